@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE itself.
+
+Runs only in the development container (needs /root/reference); the GPU box never sees the
+reference, only the .npz files this script writes.  Nothing from the reference is copied:
+its two model files are imported from where they lie, called on seeded inputs, and the
+inputs + outputs are stored.
+
+The reference imports `pem_core` (not installed, not in-tree: uv.lock:1655-1657).  The three
+names the model files read from it are supplied by an in-memory module: the constant
+TORR_2_PA (value recorded in every fixture), the `Dataset`/`ArrayLike` typing aliases, and
+`get_logger`.  See SURVEY.md §8c.
+
+Usage:  python tests/golden/make_golden.py           (rewrites tests/golden/*.npz)
+"""
+import importlib.util
+import json
+import logging
+import sys
+import types
+from pathlib import Path
+
+sys.dont_write_bytecode = True   # never leave __pycache__ inside the read-only reference tree
+
+import numpy as np
+
+REF = Path('/root/reference/src/hallmd')
+OUT = Path(__file__).resolve().parent
+TORR_2_PA = 133.322          # assumed value of pem_core.constants.TORR_2_PA
+
+
+def _load_reference():
+    pc = types.ModuleType('pem_core')
+    pc.get_logger = lambda name: logging.getLogger(name)
+    const = types.ModuleType('pem_core.constants')
+    const.TORR_2_PA = TORR_2_PA
+    const.AVOGADRO_CONSTANT = 6.02214076e23
+    const.FUNDAMENTAL_CHARGE = 1.602176634e-19
+    const.MOLECULAR_WEIGHTS = {'Xenon': 131.293, 'Krypton': 83.798}
+    typ = types.ModuleType('pem_core.types')
+    typ.Dataset = dict
+    typ.ArrayLike = object
+    sys.modules.update({'pem_core': pc, 'pem_core.constants': const, 'pem_core.types': typ})
+
+    def load(name, path):
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+
+    cathode = load('_ref_cathode', REF / 'models' / 'cathode.py')
+    plume = load('_ref_plume', REF / 'models' / 'plume.py')
+    sys.path.insert(0, str(REF.parent))
+    import hallmd.models.thruster as thruster  # noqa: E402  (needs only yaml/json + the stand-in)
+    return cathode, plume, thruster, const
+
+
+def _save(name, **arrays):
+    arrays['TORR_2_PA'] = np.float64(TORR_2_PA)
+    np.savez(OUT / f'{name}.npz', **arrays)
+    print(f'wrote {name}.npz  ({(OUT / (name + ".npz")).stat().st_size / 1024:.0f} KiB)')
+
+
+def _plume_out(plume, inputs, radius):
+    with np.errstate(all='ignore'):
+        out = plume.current_density(dict(inputs), sweep_radius=radius)
+    res = {'out_j_ion': np.asarray(out['j_ion'], dtype=np.float64),
+           'out_div_angle': np.asarray(out['div_angle'], dtype=np.float64)}
+    if 'T_c' in out:
+        res['out_T_c'] = np.asarray(out['T_c'], dtype=np.float64)
+    coords = out['j_ion_coords']
+    res['out_coords0'] = np.asarray(coords.flat[0], dtype=np.float64)
+    res['out_coords_shape'] = np.asarray(coords.shape, dtype=np.int64)
+    return res
+
+
+def main():
+    cathode, plume, thruster, const = _load_reference()
+
+    # ---- cathode: tests/test_cathode.py:19-21 ranges, seeded --------------------------------------
+    rng = np.random.default_rng(20260101)
+    N = 1024
+    cin = {'P_b': 10 ** (rng.random(N) * 4 - 8), 'V_a': rng.random(N) * 200 + 200,
+           'T_e': rng.random(N) * 4 + 1, 'V_vac': rng.random(N) * 60,
+           'Pstar': rng.random(N) * 90e-6 + 10e-6, 'P_T': rng.random(N) * 90e-6 + 10e-6}
+    vcc = cathode.cathode_coupling(dict(cin))['V_cc']
+    _save('cathode_random', **{f'in_{k}': v for k, v in cin.items()}, out_V_cc=vcc)
+
+    # cathode edge cases: both clips, NaN propagation, huge pressure ratio, scalar call, sweep
+    ce = {'P_b':   np.array([1e-5, 1e-4, 1e-8, 1e-4, np.nan, 1e-5, 1e-3, 1e-6]),
+          'V_a':   np.array([300., 20., 300., 300., 300., 300., 300., 5.]),
+          'T_e':   np.array([3., 5., 1., 5., 3., np.nan, 5., 3.]),
+          'V_vac': np.array([30., 59., 0., 0., 30., 30., 0., 30.]),
+          'Pstar': np.array([2e-5, 1e-5, 1e-4, 1e-5, 2e-5, 2e-5, 1e-6, 2e-5]),
+          'P_T':   np.array([5e-5, 1e-5, 1e-4, 1e-5, 5e-5, 5e-5, 1e-6, 5e-5])}
+    with np.errstate(all='ignore'):
+        vcc_e = cathode.cathode_coupling(dict(ce))['V_cc']
+    scalar_in = {'P_b': 10e-6, 'V_a': 300, 'T_e': 3, 'V_vac': 30, 'Pstar': 20e-6, 'P_T': 50e-6}  # test_cathode.py:14
+    vcc_s = cathode.cathode_coupling(dict(scalar_in))['V_cc']
+    sweep_pb = 10 ** np.linspace(-6, -4, 100)                                                      # test_cathode.py:27
+    sweep_in = {'P_b': sweep_pb, 'V_a': np.full(100, 300.), 'T_e': np.full(100, 1.33), 'V_vac': np.full(100, 31.6),
+                'Pstar': np.full(100, 24.6e-6), 'P_T': np.full(100, 10.2e-6)}
+    vcc_sw = cathode.cathode_coupling(dict(sweep_in))['V_cc']
+    _save('cathode_edges', **{f'in_{k}': v for k, v in ce.items()}, out_V_cc=vcc_e,
+          scalar_out_V_cc=vcc_s, sweep_in_P_b=sweep_pb, sweep_out_V_cc=vcc_sw)
+
+    # ---- plume: tests/test_plume.py:19-31 ranges (reaches the invalid alpha1<=0 branch), 5 radii ----
+    rng = np.random.default_rng(20260102)
+    N = 96
+    pin = {'P_b': 10 ** (rng.random(N) * 4 - 8), 'c0': rng.random(N) * 0.8 + 0.1, 'c1': rng.random(N) * 0.8 + 0.1,
+           'c2': rng.random(N) * 30 - 15, 'c3': rng.random(N) + 0.1, 'c4': 10 ** (rng.random(N) * 4 + 18),
+           'c5': 10 ** (rng.random(N) * 4 + 14), 'sigma_cex': rng.random(N) * 7e-20 + 51e-20,
+           'I_B0': rng.random(N) * 6 + 2}
+    radii = rng.random(5) * 0.2 + 1
+    _save('plume_random_r5', **{f'in_{k}': v for k, v in pin.items()}, radii=radii, **_plume_out(plume, pin, radii))
+
+    # same ranges, R = 1 (squeezed), with thrust, more samples
+    rng = np.random.default_rng(20260103)
+    N = 512
+    pin = {'P_b': 10 ** (rng.random(N) * 4 - 8), 'c0': rng.random(N) * 0.8 + 0.1, 'c1': rng.random(N) * 0.8 + 0.1,
+           'c2': rng.random(N) * 30 - 15, 'c3': rng.random(N) + 0.1, 'c4': 10 ** (rng.random(N) * 4 + 18),
+           'c5': 10 ** (rng.random(N) * 4 + 14), 'sigma_cex': rng.random(N) * 7e-20 + 51e-20,
+           'I_B0': rng.random(N) * 6 + 2, 'T': rng.random(N) * 0.1 + 0.02}
+    _save('plume_random_r1', **{f'in_{k}': v for k, v in pin.items()}, radii=np.array([1.0]),
+          **_plume_out(plume, pin, 1.0))
+
+    # Appendix-A priors (pem_v0_SPT-100.yml:221-270), config-2 style inputs, R = 1 at 1.0 m
+    rng = np.random.default_rng(20260104)
+    N = 512
+    pin = {'P_b': 10 ** (rng.random(N) * 4 - 8), 'c0': rng.random(N), 'c1': rng.random(N) * 0.8 + 0.1,
+           'c2': rng.random(N) * 30 - 15, 'c3': rng.random(N) * (1.570796 - 0.2) + 0.2,
+           'c4': 10 ** (rng.random(N) * 4 + 18), 'c5': 10 ** (rng.random(N) * 4 + 14),
+           'sigma_cex': rng.random(N) * 7e-20 + 51e-20, 'I_B0': rng.random(N) * 6 + 2,
+           'T': rng.random(N) * 0.1 + 0.02}
+    _save('plume_priors_r1', **{f'in_{k}': v for k, v in pin.items()}, radii=np.array([1.0]),
+          **_plume_out(plume, pin, 1.0))
+
+    # normaliser sweep: alpha1 = c3 over [1e-3, pi/2] (c2 = 0), alpha2 = alpha1/c1 up to ~52 (c1 down to 0.03)
+    a1 = np.concatenate([np.logspace(-3, np.log10(np.pi / 2), 120), np.full(40, np.pi / 2)])
+    c1 = np.concatenate([np.tile([0.9, 0.5, 0.25, 0.1], 30), np.linspace(1.0, 0.03, 40)])
+    N = a1.size
+    pin = {'P_b': np.full(N, 1e-5), 'c0': np.full(N, 0.4), 'c1': c1, 'c2': np.zeros(N), 'c3': a1,
+           'c4': np.full(N, 1e20), 'c5': np.full(N, 1e16), 'sigma_cex': np.full(N, 55e-20),
+           'I_B0': np.full(N, 3.0), 'T': np.full(N, 0.08)}
+    _save('plume_alpha_sweep', **{f'in_{k}': v for k, v in pin.items()}, radii=np.array([1.0]),
+          **_plume_out(plume, pin, 1.0))
+
+    # edge cases: alpha1 = 0, < 0, clipped > pi/2, c0 = 0 / 1 / > 1, I_B0 = 0,
+    # P_b at both ends, NaN input, alpha2 past the reference's erfi overflow (c1 = 0.02), c1 = 0, c4 = c5 = 0
+    base = {'P_b': 1e-5, 'c0': 0.5, 'c1': 0.5, 'c2': -8.0, 'c3': 0.3, 'c4': 1e20, 'c5': 1e16,
+            'sigma_cex': 55e-20, 'I_B0': 3.0, 'T': 0.08}
+    edits = [{}, {'c2': 0., 'c3': 0.}, {'c2': 0., 'c3': -0.3}, {'c2': 0., 'c3': 0.3}, {'c2': 15., 'c3': 1.5, 'P_b': 1e-4},
+             {'c0': 0.}, {'c0': 1.}, {'c0': 1.5}, {'c0': -0.2}, {'I_B0': 0.}, {'I_B0': -1.}, {'P_b': 1e-8}, {'P_b': 1e-4},
+             {'c3': np.nan}, {'P_b': np.nan}, {'I_B0': np.nan}, {'c2': 0., 'c3': 1.5, 'c1': 0.02},
+             {'c2': 0., 'c3': 1.5, 'c1': 0.03}, {'c2': 0., 'c3': 1.5, 'c1': 0.}, {'c4': 0., 'c5': 0.},
+             {'c2': 0., 'c3': 0.24}, {'c2': 0., 'c3': 0.26}, {'c2': 0., 'c3': 1e-4}, {'c1': 1.0}, {'c1': -0.5},
+             {'sigma_cex': 0.}, {'c2': 0., 'c3': 1.5, 'c1': 0.0295}, {'c2': -15., 'c3': 0.2, 'P_b': 1e-4}]
+    pin = {k: np.array([{**base, **e}[k] for e in edits], dtype=np.float64) for k in base}
+    _save('plume_edges', **{f'in_{k}': v for k, v in pin.items()}, radii=np.array([1.0]),
+          **_plume_out(plume, pin, 1.0))
+    rr = np.array([0.5, 1.0, 2.5])
+    _save('plume_edges_r3', **{f'in_{k}': v for k, v in pin.items()}, radii=rr, **_plume_out(plume, pin, rr))
+
+    # shape semantics: all-scalar inputs (leading axis of 1), loop shape (3, 4) with R = 2, no thrust
+    sc = {k: v for k, v in base.items() if k != 'T'}
+    o_sc = _plume_out(plume, sc, 1.0)
+    rng = np.random.default_rng(20260105)
+    shp = (3, 4)
+    pin = {'P_b': 10 ** (rng.random(shp) * 4 - 8), 'c0': rng.random(shp), 'c1': rng.random(shp) * 0.8 + 0.1,
+           'c2': rng.random(shp) * 30 - 15, 'c3': rng.random(shp) * 1.3 + 0.2, 'c4': 10 ** (rng.random(shp) * 4 + 18),
+           'c5': 10 ** (rng.random(shp) * 4 + 14), 'sigma_cex': rng.random(shp) * 7e-20 + 51e-20,
+           'I_B0': rng.random(shp) * 6 + 2}
+    o_nd = _plume_out(plume, pin, np.array([0.8, 1.3]))
+    _save('plume_shapes', **{f'scalar_in_{k}': np.float64(v) for k, v in sc.items()},
+          **{f'scalar_{k}': v for k, v in o_sc.items()},
+          **{f'nd_in_{k}': v for k, v in pin.items()}, nd_radii=np.array([0.8, 1.3]),
+          **{f'nd_{k}': v for k, v in o_nd.items()})
+
+    # tests/test_plume.py:64-98 pressure sweep (total current invariant = I_B0 = 3 A)
+    ps = 10 ** np.linspace(-6, -4, 100)
+    pin = {'P_b': ps, 'c0': 0.1, 'c1': 0.7, 'c2': -8.0, 'c3': 0.2, 'c4': 1e20, 'c5': 1e16, 'sigma_cex': 55e-20, 'I_B0': 3}
+    _save('plume_pressure_sweep', in_P_b=ps, **{f'in_{k}': np.float64(v) for k, v in pin.items() if k != 'P_b'},
+          radii=np.array([1.0]), **_plume_out(plume, pin, 1))
+
+    # ---- thruster host-side pre/post-processing (thruster.py:93-181, 266-276) ---------------------------
+    fid = []
+    for mf in [(0, 0), (1, 0), (2, 2), (), (3, 1)]:
+        for cfg in [{}, {'config': {'domain': [0, 0.08], 'discharge_voltage': 300., 'cathode_coupling_voltage': 30.,
+                                    'propellant': 'Xenon'}},
+                    {'config': {'domain': [0, 0.1], 'discharge_voltage': 250., 'cathode_coupling_voltage': 12.5,
+                                'propellant': 'Krypton'}}]:
+            r = thruster._default_model_fidelity(mf, cfg)
+            fid.append({'model_fidelity': list(mf), 'json_config': cfg, 'result': r})
+    # path-blazing conversion (tests/test_thruster.py:43-67 style, our own inputs)
+    p2j = {'a': ['config', 'x'], 'b': ['config', 'lst', 2], 'c': ['config', 'deep', 'er', 1, 'leaf'],
+           'o1': ['output', 'average', 'thrust'], 'o2': ['output', 'average', 'ui', 0], 'o3': ['output', 'missing', 'q']}
+    jd = {'config': {'keep': 1, 'lst': [0, 1, 2]}}
+    thruster._convert_to_julia({'a': 1.5, 'b': 'two', 'c': [3, 4]}, jd, p2j)
+    try:   # a list-index LEAF is not blazed: the reference raises IndexError (thruster.py:118)
+        thruster._convert_to_julia({'b': 1}, {'config': {}}, p2j)
+        leaf_error = None
+    except Exception as e:
+        leaf_error = type(e).__name__
+    try:
+        thruster._convert_to_julia({'zz': 1}, {}, p2j)
+        key_error = None
+    except Exception as e:
+        key_error = type(e).__name__
+    back = thruster._convert_to_pem({'output': {'average': {'thrust': 0.08, 'ui': [[1., 2., 3.]]}}}, p2j)
+    fmt = thruster._format_hallthruster_jl_input(
+        {'V_a': 310.0, 'a_1': 0.01, 'a_2': 20.0, 'V_cc': 25.0, 'mdot_a': 5e-6}, thruster.PEM_TO_JULIA,
+        thruster={'name': 'X'}, config={'anom_model': {'type': 'LogisticPressureShift',
+                                                        'model': {'type': 'TwoZoneBohm', 'c1': 0.00625, 'c2': 0.0625}},
+                                         'domain': [0, 0.08], 'propellant': 'Xenon'},
+        simulation={'duration': 0.002}, postprocess={}, model_fidelity=(1, 0))
+    fmt_g = thruster._format_hallthruster_jl_input(
+        {'anom_max': 50.0, 'anom_min': 0.005}, thruster.PEM_TO_JULIA, thruster=None,
+        config={'anom_model': {'type': 'GaussianBohm', 'hall_min': 0.00625, 'hall_max': 0.0625}},
+        model_fidelity=None)
+    with open(OUT / 'thruster_host.json', 'w') as fd:
+        json.dump({'fidelity': fid, 'convert_map': p2j, 'convert_to_julia': jd, 'convert_to_pem': back,
+                   'format_twozone': fmt, 'format_gaussian': fmt_g,
+                   'leaf_index_error': leaf_error, 'unknown_key_error': key_error, 'PEM_TO_JULIA_keys': sorted(thruster.PEM_TO_JULIA),
+                   'constants': {'AVOGADRO_CONSTANT': const.AVOGADRO_CONSTANT,
+                                 'FUNDAMENTAL_CHARGE': const.FUNDAMENTAL_CHARGE,
+                                 'MOLECULAR_WEIGHTS': const.MOLECULAR_WEIGHTS}}, fd, indent=1)
+    print('wrote thruster_host.json')
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,173 @@
+"""Pin the CPU oracle (oracle/pem_oracle.c) to golden vectors produced by running the reference.
+
+Tolerances: the oracle follows the reference operation for operation except the normaliser
+(Gauss-Legendre instead of complex erfi).  5e-12 relative is asked of it -- 20x inside the 1e-10
+the GPU path is held to (BASELINE.json north_star).  It cannot be much tighter: j_cex contains
+1 - exp(-r*n*sigma) (plume.py:95-96) with r*n*sigma down to 5e-5 under the PEM-v0 priors, so a
+one-ulp difference between numpy's SIMD exp and libm's exp is a 1e-12 relative change of j_cex.
+"""
+import json
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, div_err, load_golden, rel_err
+from oracle import oracle_ctypes as oc
+from oracle import pem_oracle_np as onp
+
+TOL = 5e-12
+PLUME_KEYS = ('P_b', 'c0', 'c1', 'c2', 'c3', 'c4', 'c5', 'sigma_cex', 'I_B0')
+
+
+def _plume_inputs(g, prefix='in_'):
+    return [g[prefix + k] for k in PLUME_KEYS]
+
+
+def test_cathode_random():
+    g = load_golden('cathode_random')
+    got = oc.cathode(g['in_P_b'], g['in_V_a'], g['in_T_e'], g['in_V_vac'], g['in_Pstar'], g['in_P_T'], float(g['TORR_2_PA']))
+    # identical operation order and no FMA: bit-for-bit except where libm log differs from numpy's by an ulp
+    assert rel_err(got, g['out_V_cc']) <= 4e-16
+    assert np.all(got >= 0) and np.all(got <= 100)          # tests/test_cathode.py:24
+
+
+def test_cathode_edges_scalar_sweep():
+    g = load_golden('cathode_edges')
+    k = float(g['TORR_2_PA'])
+    got = oc.cathode(g['in_P_b'], g['in_V_a'], g['in_T_e'], g['in_V_vac'], g['in_Pstar'], g['in_P_T'], k)
+    assert rel_err(got, g['out_V_cc']) <= 4e-16
+    assert np.isnan(got[4]) and np.isnan(got[5])              # NaN propagates
+    assert got[1] == 20.0 and got[7] == 5.0                    # clipped to V_a
+    s = oc.cathode(10e-6, 300, 3, 30, 20e-6, 50e-6, k)         # tests/test_cathode.py:14
+    assert rel_err(s, g['scalar_out_V_cc']) <= 4e-16
+    sw = oc.cathode(g['sweep_in_P_b'], 300, 1.33, 31.6, 24.6e-6, 10.2e-6, k)   # tests/test_cathode.py:27-31
+    assert rel_err(sw, g['sweep_out_V_cc']) <= 4e-16
+    assert np.all(sw >= 0) and np.all(sw <= 100)
+
+
+@pytest.mark.parametrize('name', ['plume_random_r1', 'plume_priors_r1', 'plume_alpha_sweep', 'plume_random_r5',
+                                  'plume_edges', 'plume_edges_r3'])
+def test_plume_against_reference(name):
+    g = load_golden(name)
+    T = g.get('in_T')
+    out = oc.plume(*_plume_inputs(g), float(g['TORR_2_PA']), T=T, radii=g['radii'])
+    R = g['radii'].size
+    j = out['j_ion'] if R > 1 else out['j_ion'][:, :, 0]
+    div = out['div_angle'] if R > 1 else out['div_angle'][:, 0]
+    assert rel_err(j, g['out_j_ion']) <= TOL
+    assert div_err(div, g['out_div_angle']) <= TOL
+    if T is not None:
+        tc = out['T_c'] if R > 1 else out['T_c'][:, 0]
+        assert rel_err(tc, g['out_T_c'], floor=1e-6) <= TOL
+    # invalid samples are exactly the rows the reference filled with 1e-20
+    ref_inv = np.all(g['out_j_ion'].reshape(len(out['invalid']), -1) == 1e-20, axis=1)
+    assert np.array_equal(out['invalid'], ref_inv)
+    if name == 'plume_random_r5':                              # tests/test_plume.py:35,43-44
+        assert j.shape == (96, 91, 5) and j.min() >= 0 and j.max() <= 5e3
+
+
+def test_plume_edge_semantics():
+    """SURVEY.md Appendix B items 6-8 as observed on the reference (rows of plume_edges)."""
+    g = load_golden('plume_edges')
+    out = oc.plume(*_plume_inputs(g), float(g['TORR_2_PA']), T=g['in_T'])
+    j, div, inv = out['j_ion'][:, :, 0], out['div_angle'][:, 0], out['invalid']
+    assert inv[1] and np.all(j[1] == 1e-20) and np.isnan(div[1])            # alpha1 == 0
+    assert inv[2] and np.all(j[2] == 1e-20) and np.isfinite(div[2])         # alpha1 < 0: div from the raw beams
+    assert div[2] == pytest.approx(div[3], rel=1e-14)                        # D is even in alpha
+    assert inv[7] and inv[9]                                                 # c0 > 1, I_B0 = 0
+    assert np.isnan(j[16]).all() and not inv[16]                             # alpha2 beyond the erfi overflow
+    assert np.isfinite(j[17]).all()                                          # alpha2 = 50 still finite
+
+
+def test_plume_shapes_and_pressure_sweep():
+    g = load_golden('plume_shapes')
+    k = float(g['TORR_2_PA'])
+    out = oc.plume(*[g['scalar_in_' + x] for x in PLUME_KEYS], k)
+    assert g['scalar_out_j_ion'].shape == (1, 91)                            # Appendix B item 2
+    assert rel_err(out['j_ion'][:, :, 0], g['scalar_out_j_ion']) <= TOL
+    ins = [g['nd_in_' + x].ravel() for x in PLUME_KEYS]
+    out = oc.plume(*ins, k, radii=g['nd_radii'])
+    assert g['nd_out_j_ion'].shape == (3, 4, 91, 2)                          # Appendix B item 3
+    assert rel_err(out['j_ion'].reshape(3, 4, 91, 2), g['nd_out_j_ion']) <= TOL
+    assert div_err(out['div_angle'].reshape(3, 4, 2), g['nd_out_div_angle']) <= TOL
+    assert np.array_equal(g['nd_out_coords_shape'], [3, 4])
+    assert np.array_equal(oc.angle_grid(), g['nd_out_coords0'])              # bit-exact np.linspace grid
+
+    g = load_golden('plume_pressure_sweep')                                  # tests/test_plume.py:64-98
+    out = oc.plume(g['in_P_b'], g['in_c0'], g['in_c1'], g['in_c2'], g['in_c3'], g['in_c4'], g['in_c5'],
+                   g['in_sigma_cex'], g['in_I_B0'], float(g['TORR_2_PA']))
+    j = out['j_ion'][:, :, 0]
+    assert rel_err(j, g['out_j_ion']) <= TOL
+    from scipy.integrate import simpson
+    theta = np.linspace(0, np.pi / 2, 91)
+    cur = 2 * np.pi * simpson(j * np.sin(theta), x=theta, axis=-1)
+    assert np.sqrt(np.sum((cur - cur.mean()) ** 2) / np.sum(cur ** 2)) < 1e-4
+    assert np.allclose(cur, 3.0, rtol=2e-4)                                  # total current = I_B0
+
+
+def test_normaliser_three_ways():
+    a = np.concatenate([np.logspace(-3, np.log10(53.0), 160), [0.24, 0.25, 0.26, np.pi / 2, 15.7, 53.28]])
+    d_c = oc.normaliser(a)
+    d_erfi = onp.normaliser_erfi(a)
+    assert np.all(d_erfi.imag == 0)
+    assert rel_err(d_c, d_erfi.real) <= 2e-13
+    d_q = np.array([onp.normaliser_quad(x) for x in a])
+    assert rel_err(d_c, d_q) <= 2e-13
+    assert rel_err(oc.normaliser(-a), d_c) == 0.0
+    assert np.isnan(oc.normaliser(0.0)) and np.isnan(oc.normaliser(53.3)) and np.isnan(oc.normaliser(np.nan))
+    with np.errstate(all='ignore'):
+        assert np.isfinite(onp.normaliser_erfi(53.28349511409265)) and not np.isfinite(onp.normaliser_erfi(53.2835))
+
+
+def test_thruster_stage_formulas():
+    """tests/sim_hallthruster.jl:35-48 holds no numbers; check the restatement against the formulas in numpy."""
+    rng = np.random.default_rng(5)
+    n = 257
+    Va, Vcc = rng.uniform(200, 400, n), rng.uniform(0, 60, n)
+    md, a1 = rng.uniform(2e-6, 7e-6, n), 10 ** rng.uniform(-2.5, -1, n)
+    o = oc.thruster(Va, Vcc, md, a1)
+    q, mi = 1.6e-19, 2.18e-25
+    v = np.sqrt(2 * q * (Va - Vcc) / mi)
+    assert np.array_equal(o['I_B0'], (q / mi) * md)
+    assert np.array_equal(o['v_exh'], v)
+    assert np.array_equal(o['T'], md * v)
+    assert np.array_equal(o['eta_c'], 1 - a1 * 2) and np.array_equal(o['eta_m'], 1 - a1 * 5)
+    assert np.array_equal(o['I_d'], o['I_B0'] / o['eta_c'])
+    assert rel_err(o['eta_a'], 0.5 * o['T'] ** 2 / (md * Va * o['I_d'])) <= 4e-16
+    z, u = oc.thruster_uion(v[:3], 0.0, 0.08, 102)
+    assert np.allclose(z, np.linspace(0, 0.08, 102), rtol=4e-16, atol=0)
+    assert rel_err(u, v[:3, None] / (1 + np.exp(-100 * (z - 0.04)))) <= 1e-15
+
+
+def test_coupled_is_composition():
+    rng = np.random.default_rng(6)
+    n = 300
+    x = {'P_b': 10 ** rng.uniform(-8, -4, n), 'V_a': rng.uniform(200, 400, n), 'T_e': rng.uniform(1, 5, n),
+         'V_vac': rng.uniform(0, 60, n), 'Pstar': rng.uniform(10e-6, 100e-6, n), 'P_T': rng.uniform(10e-6, 100e-6, n),
+         'mdot_a': rng.uniform(2e-6, 7e-6, n), 'a_1': 10 ** rng.uniform(-2.5, -1, n), 'c0': rng.uniform(0, 1, n),
+         'c1': rng.uniform(0.1, 0.9, n), 'c2': rng.uniform(-15, 15, n), 'c3': rng.uniform(0.2, 1.570796, n),
+         'c4': 10 ** rng.uniform(18, 22, n), 'c5': 10 ** rng.uniform(14, 18, n), 'sigma_cex': rng.uniform(51e-20, 58e-20, n)}
+    k = 133.322
+    o = oc.coupled(x, k)
+    vcc = oc.cathode(x['P_b'], x['V_a'], x['T_e'], x['V_vac'], x['Pstar'], x['P_T'], k)
+    th = oc.thruster(x['V_a'], vcc, x['mdot_a'], x['a_1'])
+    pl = oc.plume(x['P_b'], x['c0'], x['c1'], x['c2'], x['c3'], x['c4'], x['c5'], x['sigma_cex'], th['I_B0'], k, T=th['T'])
+    assert np.array_equal(o['V_cc'], vcc) and np.array_equal(o['I_B0'], th['I_B0']) and np.array_equal(o['T'], th['T'])
+    assert np.array_equal(o['j_ion'], pl['j_ion'][:, :, 0]) and np.array_equal(o['div_angle'], pl['div_angle'][:, 0])
+    assert np.array_equal(o['T_c'], pl['T_c'][:, 0])
+
+
+def test_model_fidelity_against_reference():
+    with open(GOLDEN / 'thruster_host.json') as fd:
+        g = json.load(fd)
+    c = g['constants']
+    for case in g['fidelity']:
+        mf = tuple(case['model_fidelity']) or (2, 2)
+        cfg = case['json_config'].get('config', {})
+        prop = cfg.get('propellant', 'Xenon')
+        got = oc.model_fidelity(mf[0], mf[1], float(cfg.get('domain', [0, 0.08])[1]), cfg.get('discharge_voltage', 300),
+                                cfg.get('cathode_coupling_voltage', 0), c['MOLECULAR_WEIGHTS'][prop],
+                                c['AVOGADRO_CONSTANT'], c['FUNDAMENTAL_CHARGE'])
+        want = case['result']
+        assert got['num_cells'] == want['num_cells'] and got['ncharge'] == want['ncharge']
+        assert got['dt'] == pytest.approx(want['dt'], rel=4e-16)
