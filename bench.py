@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- coupled PEM-v0 (cathode -> thruster test double -> plume) evaluations per second on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic Monte-Carlo samples already resident in HBM:
+a single `pem_coupled_f64_dev` launch over this rank's shard (BASELINE.json configs[2]: 1e7 coupled samples
+sharded over 8 GPUs = 1.25e6 samples per GPU; the same per-GPU shard is used at every N, so scaling is weak),
+followed at N > 1 by one RCCL all-gather of the reduced QoIs (V_cc, div_angle, T_c), the path's only exchange.
+
+Prints ONE JSON line on rank 0 with the fields the driver expects plus
+  "roofline":     the coupled kernel against the HBM roofline -- achieved = 872 algorithmic bytes per
+                  evaluation x samples per launch / the kernel's mean duration, measured
+                  here with HIP events on the stream the kernel runs on (torch's current stream);
+  "cpu_baseline": the CPU oracle (a C restatement of the reference's NumPy path, OpenMP) timed on this host on
+                  a bounded sample of the same workload -- reported for context, not a target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+SAMPLES_PER_GPU = 1_250_000    # BASELINE.json configs[2]: 1e7 coupled samples / 8 GPUs
+
+
+def synth_inputs(batch, seed, rank):
+    """Fill the batch with draws from the PEM-v0 priors (pem_v0_SPT-100.yml) on device."""
+    import torch
+    g = torch.Generator(device=batch.device)
+    g.manual_seed(seed * 1000 + rank)
+    u = torch.rand((15, batch.n), dtype=torch.float64, device=batch.device, generator=g)
+    x = batch.inputs
+    x[0] = 10 ** (u[0] * 4 - 8)                  # P_b      Torr, log-uniform over the domain (yml:9-17)
+    x[1] = u[1] * 200 + 200                      # V_a      V
+    x[2] = u[2] * 4 + 1                          # T_e      eV
+    x[3] = u[3] * 60                             # V_vac    V
+    x[4] = u[4] * 90e-6 + 10e-6                  # Pstar    Torr
+    x[5] = u[5] * 90e-6 + 10e-6                  # P_T      Torr
+    x[6] = u[6] * 5e-6 + 2e-6                    # mdot_a   kg/s
+    x[7] = 10 ** (u[7] * 1.5 - 2.5)              # a_1      LogUniform(0.00316, 0.1)
+    x[8] = u[8]                                  # c0
+    x[9] = u[9] * 0.8 + 0.1                      # c1
+    x[10] = u[10] * 30 - 15                      # c2
+    x[11] = u[11] * (1.570796 - 0.2) + 0.2       # c3
+    x[12] = 10 ** (u[12] * 4 + 18)               # c4
+    x[13] = 10 ** (u[13] * 4 + 14)               # c5
+    x[14] = u[14] * 7e-20 + 51e-20               # sigma_cex
+    del u
+
+
+def cpu_baseline(target_seconds=8.0):
+    """Time the CPU oracle (OpenMP over all host cores) on a bounded sample of the same coupled workload."""
+    import numpy as np
+    from oracle import oracle_ctypes as oc
+    sys.path.insert(0, str(ROOT / 'tests'))
+    from _inputs import coupled_inputs
+    threads = oc.set_threads(os.cpu_count() or 1)
+    probe = coupled_inputs(20_000, seed=9)
+    oc.coupled(probe, 133.322)                       # warm-up: tables, thread pool, page faults
+    t0 = time.perf_counter()
+    oc.coupled(probe, 133.322)
+    rate = 20_000 / (time.perf_counter() - t0)
+    n = int(min(max(rate * target_seconds, 50_000), 4_000_000))
+    x = coupled_inputs(n, seed=10)
+    t0 = time.perf_counter()
+    out = oc.coupled(x, 133.322)
+    dt = time.perf_counter() - t0
+    assert np.isfinite(out['V_cc']).all()
+    return {'value': n / dt, 'unit': 'evals/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{n} coupled samples (same priors, fp64, 91 angles), {dt:.2f} s wall on {threads} OpenMP threads'}
+
+
+def read_committed_traffic(n):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), if they were taken at this n."""
+    for f in sorted((ROOT / 'profiles').glob('traffic_r*.json'), reverse=True):
+        try:
+            rec = json.loads(f.read_text())
+            if int(rec.get('samples_per_launch', -1)) == int(n):
+                return float(rec['hbm_bytes_per_launch'])
+        except Exception:
+            continue
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--samples-per-gpu', type=int, default=SAMPLES_PER_GPU)
+    ap.add_argument('--lanes', type=int, default=0, help='lanes per sample of the kernel (0 = library default)')
+    ap.add_argument('--gather', choices=['qoi', 'full', 'none'], default='qoi',
+                    help='what the N>1 all-gather moves: reduced QoIs (24 B/sample), full profiles, or nothing')
+    ap.add_argument('--no-profile', action='store_true', help='reduced-QoI mode: never write j_ion (144 B/eval)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--seed', type=int, default=2)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from hallthrusterpem_amd import _lib
+    from hallthrusterpem_amd.batch import CoupledBatch
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    lib = _lib.load()
+    _lib.require_device()
+    lanes = lib.pem_set_lanes_per_sample(args.lanes)
+    n = args.samples_per_gpu
+    batch = CoupledBatch(n, profile=not args.no_profile)
+    synth_inputs(batch, args.seed, rank)
+    gathered = None
+    if world > 1 and args.gather == 'qoi':
+        gathered = torch.empty((world,) + tuple(batch.qoi.shape), dtype=torch.float64, device=batch.device)
+    elif world > 1 and args.gather == 'full':
+        gathered = torch.empty((world,) + tuple(batch.j_ion.shape), dtype=torch.float64, device=batch.device)
+
+    def step():
+        batch.run()
+        if gathered is not None:
+            dist.all_gather_into_tensor(gathered, batch.qoi if args.gather == 'qoi' else batch.j_ion)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=batch.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # kernel-only duration: HIP events on the launch stream around each launch (outside the timed region)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(args.steps, 50))]
+    for a, b in evs:
+        a.record()
+        batch.run()
+        b.record()
+    torch.cuda.synchronize()
+    kern_ms = sorted(a.elapsed_time(b) for a, b in evs)
+    kern_mean_ms = sum(kern_ms) / len(kern_ms)
+    frac_invalid = float(batch.invalid.float().mean().item())
+
+    if rank == 0:
+        bytes_per_launch = batch.bytes_per_eval * n
+        achieved = bytes_per_launch / (kern_mean_ms * 1e-3) / 1e9
+        traffic = read_committed_traffic(n) if not args.no_profile else None
+        line = {
+            'metric': 'coupled PEM-v0 model evals/sec', 'value': world * n * args.steps / elapsed, 'unit': 'evals/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'coupled cathode->thruster(analytic test double)->plume forward UQ, '
+                                   'BASELINE configs[2] shard (1e7 samples / 8 GPUs), 91 angles, R=1 at 1.0 m',
+                       'samples_per_gpu': n, 'global_samples_per_step': world * n, 'seed': args.seed,
+                       'TORR_2_PA': 133.322, 'lanes_per_sample': lanes, 'profile_written': not args.no_profile,
+                       'gather': args.gather if world > 1 else 'none', 'parallelism': f'sample-shard x{world}',
+                       'invalid_fraction': frac_invalid},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'kernel': 'plume_r1_kernel<L,COUPLED,WRITE_J>', 'kernel_ms_mean': kern_mean_ms,
+                         'kernel_ms_min': kern_ms[0], 'bytes_per_eval': batch.bytes_per_eval,
+                         'bytes_per_launch': bytes_per_launch},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline()
+        else:
+            line['cpu_baseline'] = None
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,83 @@
+"""ctypes binding of libpem_hip.so (C ABI declared in include/pem_hip.h).
+
+There is deliberately no CPU fallback here: if the shared library is missing, or no HIP device is
+present, the model functions raise.  The CPU oracle under oracle/ is test infrastructure and is
+never imported from this package.
+"""
+import ctypes as C
+import threading
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+LIB_PATH = PKG / 'libpem_hip.so'
+
+PEM_OK, PEM_ERR_INVALID_ARG, PEM_ERR_HIP, PEM_ERR_NO_DEVICE = 0, 1, 2, 3
+NANGLE = 91
+
+_dp = C.c_void_p          # every array crosses the boundary as a raw pointer
+_sz = C.c_size_t
+_f8 = C.c_double
+
+# name -> (restype, argtypes); one entry per declaration in include/pem_hip.h
+SIGNATURES = {
+    'pem_version': (C.c_char_p, []),
+    'pem_last_error': (C.c_char_p, []),
+    'pem_device_count': (C.c_int, []),
+    'pem_init': (C.c_int, [C.c_int]),
+    'pem_synchronize': (C.c_int, [_dp]),
+    'pem_set_lanes_per_sample': (C.c_int, [C.c_int]),
+    'pem_angle_grid': (C.POINTER(C.c_double), []),
+    'pem_cathode_f64_dev': (C.c_int, [_sz] + [_dp] * 6 + [_f8, _dp, _dp]),
+    'pem_cathode_f64': (C.c_int, [_sz] + [_dp] * 6 + [_f8, _dp]),
+    'pem_plume_f64_dev': (C.c_int, [_sz, C.c_int, _dp, _f8] + [_dp] * 10 + [_dp] * 4 + [_dp]),
+    'pem_plume_f64': (C.c_int, [_sz, C.c_int, _dp, _f8] + [_dp] * 10 + [_dp] * 4),
+    'pem_thruster_f64_dev': (C.c_int, [_sz] + [_dp] * 4 + [_dp] * 8 + [_dp]),
+    'pem_thruster_f64': (C.c_int, [_sz] + [_dp] * 4 + [_dp] * 8),
+    'pem_coupled_f64_dev': (C.c_int, [_sz, _f8, _f8] + [_dp] * 15 + [_dp] * 7 + [_dp]),
+    'pem_coupled_f64': (C.c_int, [_sz, _f8, _f8] + [_dp] * 15 + [_dp] * 7),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class PemHipError(RuntimeError):
+    """A libpem_hip entry point returned a non-zero status."""
+
+    def __init__(self, code, message):
+        super().__init__(f'libpem_hip error {code}: {message}')
+        self.code = code
+
+
+def load():
+    """Load libpem_hip.so (building it with hipcc if the sources are newer) and bind every symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not LIB_PATH.exists():
+            from . import build as _build
+            _build.build()
+        lib = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)     # AttributeError here = the library does not match the header
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int):
+    if rc != PEM_OK:
+        raise PemHipError(rc, load().pem_last_error().decode(errors='replace'))
+
+
+def device_count() -> int:
+    return int(load().pem_device_count())
+
+
+def require_device():
+    if device_count() < 1:
+        raise PemHipError(PEM_ERR_NO_DEVICE, 'no HIP device visible; hallthrusterpem_amd has no CPU path')

@@ -1,0 +1,68 @@
+"""Preallocated device-resident batches: the unit of work of the Monte-Carlo / Sobol' sampling loops.
+
+A `CoupledBatch` owns the 15 SoA input arrays and the output arrays of `n` samples in HBM and evaluates
+them with one `pem_coupled_f64_dev` launch on torch's current stream -- no allocation, no host copy and
+no Python marshalling beyond one ctypes call per launch.  torch is used for device memory and streams only.
+"""
+import ctypes as C
+
+from . import _lib, constants
+from .models.coupled import COUPLED_INPUTS
+
+QOI_NAMES = ('V_cc', 'div_angle', 'T_c')      # the reduced QoIs gathered across GPUs (24 B / sample)
+
+# algorithmic HBM bytes per evaluation, fp64
+BYTES_PER_EVAL_COUPLED = 15 * 8 + (1 + 91 + 1 + 1) * 8          # 872
+BYTES_PER_EVAL_REDUCED = 15 * 8 + 3 * 8                         # 144
+BYTES_PER_EVAL_PLUME = 9 * 8 + (91 + 1) * 8                     # 808 (824 with T -> T_c)
+BYTES_PER_EVAL_CATHODE = 7 * 8                                  # 56
+
+
+class CoupledBatch:
+    def __init__(self, n: int, device=None, profile: bool = True, sweep_radius: float = 1.0):
+        import torch
+        _lib.load()
+        _lib.require_device()
+        self.n = int(n)
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.profile = bool(profile)
+        self.radius = float(sweep_radius)
+        f64 = dict(dtype=torch.float64, device=self.device)
+        self.inputs = torch.empty((len(COUPLED_INPUTS), self.n), **f64)         # SoA: one row per variable
+        self.qoi = torch.empty((len(QOI_NAMES), self.n), **f64)                  # V_cc, div_angle, T_c
+        self.I_B0 = torch.empty(self.n, **f64)
+        self.T = torch.empty(self.n, **f64)
+        self.j_ion = torch.empty((self.n, _lib.NANGLE), **f64) if self.profile else None
+        self.invalid = torch.empty(self.n, dtype=torch.uint8, device=self.device)
+        self._bind()
+
+    def _bind(self):
+        p = lambda t: C.c_void_p(t.data_ptr())                                   # noqa: E731
+        self._in_ptrs = [p(self.inputs[i]) for i in range(len(COUPLED_INPUTS))]
+        self._out_ptrs = [p(self.qoi[0]), p(self.I_B0), p(self.T), p(self.j_ion) if self.profile else None,
+                          p(self.qoi[1]), p(self.qoi[2]), p(self.invalid)]
+
+    def set_inputs(self, values: dict):
+        """Copy a dict of arrays/tensors (keys = COUPLED_INPUTS) into the batch."""
+        import torch
+        for i, k in enumerate(COUPLED_INPUTS):
+            self.inputs[i].copy_(torch.as_tensor(values[k], dtype=torch.float64).to(self.device).expand(self.n))
+
+    def run(self, stream=None):
+        """Enqueue one coupled evaluation of the whole batch (asynchronous)."""
+        import torch
+        s = torch.cuda.current_stream(self.device) if stream is None else stream
+        rc = _lib.load().pem_coupled_f64_dev(self.n, constants.TORR_2_PA, self.radius, *self._in_ptrs,
+                                             *self._out_ptrs, C.c_void_p(s.cuda_stream))
+        _lib.check(rc)
+
+    def outputs(self) -> dict:
+        out = {'V_cc': self.qoi[0], 'div_angle': self.qoi[1], 'T_c': self.qoi[2], 'I_B0': self.I_B0, 'T': self.T,
+               'invalid': self.invalid.bool()}
+        if self.profile:
+            out['j_ion'] = self.j_ion
+        return out
+
+    @property
+    def bytes_per_eval(self) -> int:
+        return BYTES_PER_EVAL_COUPLED if self.profile else BYTES_PER_EVAL_REDUCED

@@ -1,0 +1,118 @@
+/*
+ * pem_hip.h -- C ABI of libpem_hip.so: the MI355X (gfx950) batched evaluator for the PEM-v0
+ * cathode -> thruster -> plume sub-models of JANUS-Institute/HallThrusterPEM (hallmd 0.3.0).
+ *
+ * Every entry point replaces one vectorised Python model callable of the reference (paths are
+ * relative to the upstream repository root).  The reference has no FFI of its own -- its models
+ * are NumPy functions called as  model(inputs: dict[str, ndarray]) -> dict[str, ndarray]  by amisc
+ * (scripts/pem_v0/pem_v0_SPT-100.yml:6,63,216) -- so the boundary is drawn one level below that
+ * call: plain fp64 SoA buffers, one value per Monte-Carlo sample, caller-owned outputs.
+ *
+ *   pem_cathode_f64*    src/hallmd/models/cathode.py:16-38      cathode_coupling()
+ *   pem_plume_f64*      src/hallmd/models/plume.py:21-159       current_density()
+ *   pem_thruster_f64*   tests/sim_hallthruster.jl:35-48         the reference's analytic stand-in
+ *                        for HallThruster.jl (a TEST DOUBLE of the thruster stage; the 1-D fluid
+ *                        solver itself is a third-party Julia program and out of scope)
+ *   pem_coupled_f64*    the three stages fused, wired as pem_v0_SPT-100.yml wires the components
+ *                        (V_cc: cathode -> thruster; I_B0: thruster -> plume; T -> T_c)
+ *
+ * Conventions
+ *   - All arrays are contiguous fp64 of length n (one entry per sample) unless stated.
+ *   - `*_dev` functions take DEVICE pointers (HBM of the current HIP device) and enqueue on
+ *     `stream` (a hipStream_t passed as void*; NULL = the default stream) without synchronising.
+ *     Functions without the suffix take HOST pointers, stage through device memory and return
+ *     after the results are back in the caller's buffers.
+ *   - Nothing is retained past the call.  Inputs are never written.
+ *   - j_ion is laid out [n][91][n_radii] (row-major), exactly numpy's (..., 91, R) result of
+ *     plume.py:102; angle k is k degrees from the thruster centreline (plume.py:53).
+ *   - Physics failures are data, not errors, as in the reference: an invalid plume sample
+ *     (alpha1 <= 0 or any j_ion <= 0, plume.py:105) has its j_ion row set to 1e-20 and, if
+ *     `invalid` is non-NULL, invalid[i] = 1.  NaN inputs propagate.
+ *   - `torr2pa` is pem_core.constants.TORR_2_PA, which the reference imports from an
+ *     un-vendored package (cathode.py:10, plume.py:12); it is a run-time argument here.
+ *   - Return value: PEM_OK or a PEM_ERR_* code; pem_last_error() describes the last failure on
+ *     the calling thread.  There is no CPU fallback: without a HIP device every compute entry
+ *     point fails with PEM_ERR_NO_DEVICE.
+ */
+#ifndef PEM_HIP_H
+#define PEM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PEM_NANGLE 91 /* points of the fixed 0..90 degree sweep, plume.py:53 */
+
+#define PEM_OK 0
+#define PEM_ERR_INVALID_ARG 1
+#define PEM_ERR_HIP 2
+#define PEM_ERR_NO_DEVICE 3
+
+typedef void* pem_stream_t; /* hipStream_t */
+
+/* ---- library state ------------------------------------------------------------------------- */
+const char* pem_version(void);
+const char* pem_last_error(void);
+int pem_device_count(void);                 /* number of HIP devices, 0 if none / no driver        */
+int pem_init(int device);                   /* hipSetDevice(device) + upload the constant tables   */
+int pem_synchronize(pem_stream_t stream);   /* hipStreamSynchronize                                */
+/* Tuning knob of the plume/coupled kernels: lanes that share one sample (1, 2, 4, 8 or 16).
+ * 0 restores the default.  Returns the value in effect. */
+int pem_set_lanes_per_sample(int lanes);
+/* The 91-point angle grid (host memory, valid for the life of the library): j_ion_coords.    */
+const double* pem_angle_grid(void);
+
+/* ---- cathode_coupling  (cathode.py:16-38) --------------------------------------------------- */
+int pem_cathode_f64_dev(size_t n, const double* P_b, const double* V_a, const double* T_e,
+                        const double* V_vac, const double* Pstar, const double* P_T, double torr2pa,
+                        double* V_cc, pem_stream_t stream);
+int pem_cathode_f64(size_t n, const double* P_b, const double* V_a, const double* T_e,
+                    const double* V_vac, const double* Pstar, const double* P_T, double torr2pa,
+                    double* V_cc);
+
+/* ---- current_density  (plume.py:21-159) ------------------------------------------------------
+ * radii: HOST array of n_radii sweep radii in metres (the `sweep_radius` argument), also for the
+ * _dev form.  T / T_c: optional thrust in, corrected thrust out (plume.py:136-140); pass NULL for
+ * both to skip.  j_ion: [n][91][n_radii]; div_angle, T_c: [n][n_radii]; invalid: [n] or NULL.   */
+int pem_plume_f64_dev(size_t n, int n_radii, const double* radii, double torr2pa, const double* P_b,
+                      const double* c0, const double* c1, const double* c2, const double* c3,
+                      const double* c4, const double* c5, const double* sigma_cex, const double* I_B0,
+                      const double* T, double* j_ion, double* div_angle, double* T_c, uint8_t* invalid,
+                      pem_stream_t stream);
+int pem_plume_f64(size_t n, int n_radii, const double* radii, double torr2pa, const double* P_b,
+                  const double* c0, const double* c1, const double* c2, const double* c3,
+                  const double* c4, const double* c5, const double* sigma_cex, const double* I_B0,
+                  const double* T, double* j_ion, double* div_angle, double* T_c, uint8_t* invalid);
+
+/* ---- analytic thruster stage  (tests/sim_hallthruster.jl:35-48; a test double) ---------------
+ * Any output pointer may be NULL.                                                              */
+int pem_thruster_f64_dev(size_t n, const double* V_a, const double* V_cc, const double* mdot_a,
+                         const double* a_1, double* I_B0, double* I_d, double* T, double* eta_c,
+                         double* eta_m, double* eta_v, double* eta_a, double* v_exh, pem_stream_t stream);
+int pem_thruster_f64(size_t n, const double* V_a, const double* V_cc, const double* mdot_a,
+                     const double* a_1, double* I_B0, double* I_d, double* T, double* eta_c,
+                     double* eta_m, double* eta_v, double* eta_a, double* v_exh);
+
+/* ---- coupled cathode -> thruster -> plume, one pass, sweep radius `radius` (R = 1) -----------
+ * 15 inputs per sample; outputs V_cc, div_angle, T_c always; I_B0, T, invalid optional (NULL);
+ * j_ion optional: NULL selects the reduced-QoI mode that never writes the 91-point profile.    */
+int pem_coupled_f64_dev(size_t n, double torr2pa, double radius, const double* P_b, const double* V_a,
+                        const double* T_e, const double* V_vac, const double* Pstar, const double* P_T,
+                        const double* mdot_a, const double* a_1, const double* c0, const double* c1,
+                        const double* c2, const double* c3, const double* c4, const double* c5,
+                        const double* sigma_cex, double* V_cc, double* I_B0, double* T, double* j_ion,
+                        double* div_angle, double* T_c, uint8_t* invalid, pem_stream_t stream);
+int pem_coupled_f64(size_t n, double torr2pa, double radius, const double* P_b, const double* V_a,
+                    const double* T_e, const double* V_vac, const double* Pstar, const double* P_T,
+                    const double* mdot_a, const double* a_1, const double* c0, const double* c1,
+                    const double* c2, const double* c3, const double* c4, const double* c5,
+                    const double* sigma_cex, double* V_cc, double* I_B0, double* T, double* j_ion,
+                    double* div_angle, double* T_c, uint8_t* invalid);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PEM_HIP_H */

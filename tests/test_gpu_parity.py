@@ -1,0 +1,242 @@
+"""Parity of the HIP path (through the C ABI of libpem_hip.so) with the reference.
+
+Two checkers: the golden vectors the reference itself produced (tests/golden), and the CPU oracle
+(oracle/pem_oracle.c, pinned to those vectors by tests/test_oracle_golden.py) on seeded inputs.
+
+Tolerance (BASELINE.json north_star: "within 1e-10 rel for the analytic cathode/plume models"):
+  RTOL = 1e-10 relative on every finite output, NaN/inf patterns and invalid flags identical.
+  div_angle = arccos(cos_div) is compared with conftest.div_err (relative 1e-10 unless the difference is
+  within 8 ulp of cos_div, where arccos is ill-conditioned).
+Observed on MI355X: see DESIGN.md "Parity" (cathode <= 2e-16, plume <= ~2e-12).
+"""
+import numpy as np
+import pytest
+
+from _inputs import cathode_inputs, coupled_inputs, plume_inputs
+from conftest import div_err, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-10
+PLUME_KEYS = ('P_b', 'c0', 'c1', 'c2', 'c3', 'c4', 'c5', 'sigma_cex', 'I_B0')
+
+
+@pytest.fixture(scope='module')
+def pem():
+    import hallthrusterpem_amd as pkg
+    from hallthrusterpem_amd import _lib
+    _lib.load()
+    _lib.require_device()          # fail loudly: the GPU tier must never pass on a fallback
+    return pkg
+
+
+@pytest.fixture(scope='module')
+def oc():
+    from oracle import oracle_ctypes
+    return oracle_ctypes
+
+
+def _plume_in(g, prefix='in_'):
+    d = {k: g[prefix + k] for k in PLUME_KEYS}
+    if prefix + 'T' in g:
+        d['T'] = g[prefix + 'T']
+    return d
+
+
+# ---------------------------------------------------------------------------------------------- golden vectors
+def test_cathode_golden(pem):
+    from hallthrusterpem_amd.models import cathode_coupling
+    g = load_golden('cathode_random')
+    pem.constants.set_torr_2_pa(float(g['TORR_2_PA']))
+    out = cathode_coupling({k: g['in_' + k] for k in ('P_b', 'V_a', 'T_e', 'V_vac', 'Pstar', 'P_T')})
+    assert rel_err(out['V_cc'], g['out_V_cc']) <= RTOL
+    assert np.all(out['V_cc'] >= 0) and np.all(out['V_cc'] <= 100)                  # tests/test_cathode.py:24
+    g = load_golden('cathode_edges')
+    out = cathode_coupling({k: g['in_' + k] for k in ('P_b', 'V_a', 'T_e', 'V_vac', 'Pstar', 'P_T')})
+    assert rel_err(out['V_cc'], g['out_V_cc']) <= RTOL
+    s = cathode_coupling({'P_b': 10e-6, 'V_a': 300, 'T_e': 3, 'V_vac': 30, 'Pstar': 20e-6, 'P_T': 50e-6})
+    assert s['V_cc'].shape == (1,) and rel_err(s['V_cc'], g['scalar_out_V_cc']) <= RTOL   # test_cathode.py:14-15
+    sw = cathode_coupling({'P_b': g['sweep_in_P_b'], 'V_a': 300, 'T_e': 1.33, 'V_vac': 31.6, 'Pstar': 24.6e-6,
+                           'P_T': 10.2e-6})                                                 # test_cathode.py:27-31
+    assert rel_err(sw['V_cc'], g['sweep_out_V_cc']) <= RTOL
+    with pytest.raises(KeyError):
+        cathode_coupling({'P_b': 1e-5})
+
+
+@pytest.mark.parametrize('name', ['plume_random_r1', 'plume_priors_r1', 'plume_alpha_sweep', 'plume_random_r5',
+                                  'plume_edges', 'plume_edges_r3', 'plume_pressure_sweep'])
+def test_plume_golden(pem, name):
+    from hallthrusterpem_amd.models import current_density
+    g = load_golden(name)
+    pem.constants.set_torr_2_pa(float(g['TORR_2_PA']))
+    radii = g['radii'] if g['radii'].size > 1 else float(g['radii'][0])
+    out = current_density(_plume_in(g), sweep_radius=radii)
+    assert out['j_ion'].shape == g['out_j_ion'].shape and out['div_angle'].shape == g['out_div_angle'].shape
+    assert rel_err(out['j_ion'], g['out_j_ion']) <= RTOL
+    assert div_err(out['div_angle'], g['out_div_angle']) <= RTOL
+    if 'out_T_c' in g:
+        assert rel_err(out['T_c'], g['out_T_c']) <= RTOL
+    else:
+        assert 'T_c' not in out
+    assert out['j_ion_coords'].shape == tuple(g['out_coords_shape'])
+    assert np.array_equal(out['j_ion_coords'].flat[0], g['out_coords0'])
+    if name == 'plume_random_r5':                                                    # tests/test_plume.py:35,43-44
+        assert out['j_ion'].shape == (96, 91, 5) and out['j_ion'].min() >= 0 and out['j_ion'].max() <= 5e3
+    if name == 'plume_pressure_sweep':                                               # tests/test_plume.py:84-98
+        from scipy.integrate import simpson
+        theta = np.linspace(0, np.pi / 2, 91)
+        cur = 2 * np.pi * simpson(out['j_ion'] * np.sin(theta), x=theta, axis=-1)
+        assert np.sqrt(np.sum((cur - cur.mean()) ** 2) / np.sum(cur ** 2)) < 1e-4
+
+
+def test_plume_shapes_golden(pem):
+    from hallthrusterpem_amd.models import current_density
+    g = load_golden('plume_shapes')
+    pem.constants.set_torr_2_pa(float(g['TORR_2_PA']))
+    out = current_density({k: float(g['scalar_in_' + k]) for k in PLUME_KEYS})      # all scalars -> leading axis 1
+    assert out['j_ion'].shape == (1, 91) and out['div_angle'].shape == (1,) and out['j_ion_coords'].shape == (1,)
+    assert rel_err(out['j_ion'], g['scalar_out_j_ion']) <= RTOL
+    out = current_density({k: g['nd_in_' + k] for k in PLUME_KEYS}, sweep_radius=g['nd_radii'])
+    assert out['j_ion'].shape == (3, 4, 91, 2) and out['div_angle'].shape == (3, 4, 2)
+    assert out['j_ion_coords'].shape == (3, 4)
+    assert rel_err(out['j_ion'], g['nd_out_j_ion']) <= RTOL
+    assert div_err(out['div_angle'], g['nd_out_div_angle']) <= RTOL
+    with pytest.raises(KeyError):
+        current_density({'P_b': 1e-5})
+
+
+# ---------------------------------------------------------------------------------------------- against the oracle
+def test_cathode_config1_lhs(pem, oc):
+    """BASELINE.json configs[0]: 1e4 Latin-hypercube samples of cathode_coupling."""
+    from hallthrusterpem_amd.models import cathode_coupling
+    x = cathode_inputs(10_000, seed=0, lhs=True)
+    k = pem.constants.TORR_2_PA
+    got = cathode_coupling(x)['V_cc']
+    want = oc.cathode(x['P_b'], x['V_a'], x['T_e'], x['V_vac'], x['Pstar'], x['P_T'], k)
+    assert rel_err(got, want) <= RTOL
+
+
+@pytest.mark.parametrize('lanes', [1, 2, 4, 8])
+@pytest.mark.parametrize('n', [1, 63, 65, 1000, 4099])
+def test_plume_vs_oracle_every_variant_ragged(pem, oc, lanes, n):
+    from hallthrusterpem_amd import _lib
+    from hallthrusterpem_amd.models import current_density
+    lib = _lib.load()
+    assert lib.pem_set_lanes_per_sample(lanes) == lanes
+    try:
+        x = plume_inputs(n, seed=100 + n, priors=(n % 2 == 0))
+        out = current_density(x)
+        ref = oc.plume(*[x[k] for k in PLUME_KEYS], pem.constants.TORR_2_PA, T=x['T'])
+        assert rel_err(out['j_ion'], ref['j_ion'][:, :, 0]) <= RTOL
+        assert div_err(out['div_angle'], ref['div_angle'][:, 0]) <= RTOL
+        assert rel_err(out['T_c'], ref['T_c'][:, 0]) <= RTOL
+    finally:
+        lib.pem_set_lanes_per_sample(0)
+
+
+def test_plume_general_radii_vs_oracle(pem, oc):
+    from hallthrusterpem_amd.models import current_density
+    x = plume_inputs(777, seed=7, priors=False)
+    radii = np.random.default_rng(8).random(25) * 0.2 + 1                            # tests/test_plume.py:31
+    out = current_density(x, sweep_radius=radii)
+    ref = oc.plume(*[x[k] for k in PLUME_KEYS], pem.constants.TORR_2_PA, T=x['T'], radii=radii)
+    assert out['j_ion'].shape == (777, 91, 25)
+    assert rel_err(out['j_ion'], ref['j_ion']) <= RTOL
+    assert div_err(out['div_angle'], ref['div_angle']) <= RTOL
+    assert rel_err(out['T_c'], ref['T_c']) <= RTOL
+
+
+def test_thruster_stage_vs_oracle(pem, oc):
+    from hallthrusterpem_amd.models import thruster_analytic
+    x = coupled_inputs(5000, seed=3)
+    vcc = np.random.default_rng(4).uniform(0, 60, 5000)
+    got = thruster_analytic({'V_a': x['V_a'], 'V_cc': vcc, 'mdot_a': x['mdot_a'], 'a_1': x['a_1']})
+    want = oc.thruster(x['V_a'], vcc, x['mdot_a'], x['a_1'])
+    for k in want:
+        assert rel_err(got[k], want[k]) <= 1e-15, k        # same IEEE operations, no transcendental but sqrt
+
+
+@pytest.mark.parametrize('n', [1, 64, 100_000])
+def test_coupled_vs_oracle(pem, oc, n):
+    from hallthrusterpem_amd.models import pem_v0_coupled
+    x = coupled_inputs(n, seed=2)
+    got = pem_v0_coupled(x)
+    want = oc.coupled(x, pem.constants.TORR_2_PA)
+    assert rel_err(got['V_cc'], want['V_cc']) <= RTOL
+    assert rel_err(got['I_B0'], want['I_B0']) <= 1e-15 and rel_err(got['T'], want['T']) <= RTOL
+    assert rel_err(got['j_ion'], want['j_ion']) <= RTOL
+    assert div_err(got['div_angle'], want['div_angle']) <= RTOL
+    assert rel_err(got['T_c'], want['T_c']) <= RTOL
+    assert np.array_equal(got['invalid'], want['invalid'])
+    # reduced-QoI mode returns the same scalars without ever writing the profile
+    red = pem_v0_coupled(x, profile=False)
+    assert 'j_ion' not in red
+    for k in ('V_cc', 'I_B0', 'T', 'div_angle', 'T_c'):
+        assert np.array_equal(red[k], got[k], equal_nan=True), k
+
+
+def test_empty_batch(pem):
+    from hallthrusterpem_amd.models import cathode_coupling, current_density
+    e = np.empty(0)
+    assert cathode_coupling({k: e for k in ('P_b', 'V_a', 'T_e', 'V_vac', 'Pstar', 'P_T')})['V_cc'].shape == (0,)
+    out = current_density({k: e for k in PLUME_KEYS})
+    assert out['j_ion'].shape == (0, 91) and out['div_angle'].shape == (0,)
+
+
+# ---------------------------------------------------------------------------------------------- device-resident path
+def test_device_tensors_match_host_path(pem):
+    import torch
+    from hallthrusterpem_amd.models import cathode_coupling, current_density, pem_v0_coupled
+    x = coupled_inputs(30_001, seed=11)
+    xd = {k: torch.from_numpy(v).cuda() for k, v in x.items()}
+    h = pem_v0_coupled(x)
+    d = pem_v0_coupled(xd)
+    torch.cuda.synchronize()
+    for k in ('V_cc', 'I_B0', 'T', 'j_ion', 'div_angle', 'T_c', 'invalid'):
+        assert d[k].is_cuda
+        assert np.array_equal(d[k].cpu().numpy(), h[k], equal_nan=True), k           # same kernel: bit-identical
+    c = cathode_coupling({k: xd[k] for k in ('P_b', 'V_a', 'T_e', 'V_vac', 'Pstar', 'P_T')})['V_cc']
+    assert np.array_equal(c.cpu().numpy(), h['V_cc'])
+    p = plume_inputs(5000, seed=12)
+    pd = {k: torch.from_numpy(v).cuda() for k, v in p.items()}
+    a, b = current_density(p), current_density(pd)
+    assert np.array_equal(b['j_ion'].cpu().numpy(), a['j_ion'], equal_nan=True)
+    assert np.array_equal(b['T_c'].cpu().numpy(), a['T_c'], equal_nan=True)
+
+
+# ---------------------------------------------------------------------------------------------- full-size properties
+def test_config2_full_size_properties(pem, oc):
+    """BASELINE.json configs[1]: 1e6 MC samples of the plume model, R = 1, fp64 -- too many for the oracle in
+    seconds, so: (a) a strided 1-in-500 subsample against the oracle, (b) shard invariance (samples are
+    independent: evaluating two halves equals evaluating the whole, bit for bit), (c) determinism,
+    (d) the reference's own invariant, total current = I_B0 (tests/test_plume.py:91-98), (e) range."""
+    import torch
+    from hallthrusterpem_amd.models import current_density
+    n = 1_000_000
+    x = plume_inputs(n, seed=1, priors=True)
+    xd = {k: torch.from_numpy(v).cuda() for k, v in x.items()}
+    out = current_density(xd)
+    j = out['j_ion']
+    sub = slice(0, n, 500)
+    ref = oc.plume(*[x[k][sub] for k in PLUME_KEYS], pem.constants.TORR_2_PA, T=x['T'][sub])
+    assert rel_err(j[sub].cpu().numpy(), ref['j_ion'][:, :, 0]) <= RTOL
+    assert div_err(out['div_angle'][sub].cpu().numpy(), ref['div_angle'][:, 0]) <= RTOL
+    half = n // 2 + 17
+    lo = current_density({k: v[:half] for k, v in xd.items()})
+    hi = current_density({k: v[half:] for k, v in xd.items()})
+    assert torch.equal(torch.cat([lo['j_ion'], hi['j_ion']]), j)
+    assert torch.equal(torch.cat([lo['div_angle'], hi['div_angle']]), out['div_angle'])
+    again = current_density(xd)
+    assert torch.equal(again['j_ion'], j) and torch.equal(again['T_c'], out['T_c'])
+    assert bool((j >= 0).all()) and bool((j <= 5e3).all())
+    # total current: 2 pi R^2 Int j sin(theta) dtheta = I_B0 wherever the 1-degree Simpson rule resolves the beam
+    theta = torch.linspace(0, np.pi / 2, 91, dtype=torch.float64, device='cuda')
+    w = torch.full((91,), 2.0, dtype=torch.float64, device='cuda')
+    w[1::2] = 4.0
+    w[0] = w[-1] = 1.0
+    w *= (np.pi / 2 / 90) / 3
+    cur = 2 * np.pi * (j * torch.sin(theta) * w).sum(-1)
+    a1 = torch.clamp(xd['c2'] * xd['P_b'] * pem.constants.TORR_2_PA + xd['c3'], max=np.pi / 2)
+    resolved = a1 > 0.1
+    rel = ((cur - xd['I_B0']).abs() / xd['I_B0'])[resolved]
+    assert float(rel.max()) < 1e-4
