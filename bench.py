@@ -54,26 +54,42 @@ def synth_inputs(batch, seed, rank):
     del u
 
 
-def cpu_baseline(target_seconds=8.0):
-    """Time the CPU oracle (OpenMP over all host cores) on a bounded sample of the same coupled workload."""
+def host_cpu_share():
+    """CPUs this process may really use: affinity mask, cgroup quota, and the GPU box's 16-per-GPU share."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = Path('/sys/fs/cgroup/cpu.max').read_text().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get('PEM_CPU_THREADS', '16'))))
+
+
+def cpu_baseline(target_seconds=2.5):
+    """Time the CPU oracle (OpenMP) on a bounded sample of the same coupled workload: best of 3 runs of about
+    `target_seconds` wall each on `host_cpu_share()` threads (~20-30 s of CPU work in total)."""
     import numpy as np
     from oracle import oracle_ctypes as oc
     sys.path.insert(0, str(ROOT / 'tests'))
     from _inputs import coupled_inputs
-    threads = oc.set_threads(os.cpu_count() or 1)
-    probe = coupled_inputs(20_000, seed=9)
+    threads = oc.set_threads(host_cpu_share())
+    probe = coupled_inputs(50_000, seed=9)
     oc.coupled(probe, 133.322)                       # warm-up: tables, thread pool, page faults
     t0 = time.perf_counter()
     oc.coupled(probe, 133.322)
-    rate = 20_000 / (time.perf_counter() - t0)
-    n = int(min(max(rate * target_seconds, 50_000), 4_000_000))
+    rate = 50_000 / (time.perf_counter() - t0)
+    n = int(min(max(rate * target_seconds, 50_000), 8_000_000))
     x = coupled_inputs(n, seed=10)
-    t0 = time.perf_counter()
-    out = oc.coupled(x, 133.322)
-    dt = time.perf_counter() - t0
+    best = float('inf')
+    for _ in range(3):
+        t0 = time.perf_counter()
+        out = oc.coupled(x, 133.322)
+        best = min(best, time.perf_counter() - t0)
     assert np.isfinite(out['V_cc']).all()
-    return {'value': n / dt, 'unit': 'evals/s', 'cores': threads, 'kind': 'port',
-            'sample': f'{n} coupled samples (same priors, fp64, 91 angles), {dt:.2f} s wall on {threads} OpenMP threads'}
+    return {'value': n / best, 'unit': 'evals/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{n} coupled samples (same priors, fp64, 91 angles, full profile), best of 3 runs: '
+                      f'{best:.2f} s wall on {threads} OpenMP threads'}
 
 
 def read_committed_traffic(n):

@@ -5,6 +5,8 @@ present, the model functions raise.  The CPU oracle under oracle/ is test infras
 never imported from this package.
 """
 import ctypes as C
+import importlib.util
+import os
 import threading
 from pathlib import Path
 
@@ -38,6 +40,7 @@ SIGNATURES = {
 }
 
 _lib = None
+_hip_runtime = None
 _lock = threading.Lock()
 
 
@@ -49,9 +52,29 @@ class PemHipError(RuntimeError):
         self.code = code
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64/libhsa-runtime64.  Two HIP runtimes in one process
+    cannot both own the GPU ("No HIP GPUs are available" from whichever initialises second), and device
+    pointers/streams are only meaningful inside one runtime.  So if torch is installed, map ITS runtime
+    first: libpem_hip.so's DT_NEEDED libamdhip64.so.7 then resolves to the already-loaded SONAME.
+    Set PEM_HIP_RUNTIME=system to skip this and use /opt/rocm's runtime (numpy-only use)."""
+    if os.environ.get('PEM_HIP_RUNTIME', '').lower() == 'system':
+        return None
+    try:
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    cand = Path(list(spec.submodule_search_locations)[0]) / 'lib' / 'libamdhip64.so'
+    if not cand.exists():
+        return None
+    return C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+
+
 def load():
     """Load libpem_hip.so (building it with hipcc if the sources are newer) and bind every symbol."""
-    global _lib
+    global _lib, _hip_runtime
     if _lib is not None:
         return _lib
     with _lock:
@@ -60,6 +83,7 @@ def load():
         if not LIB_PATH.exists():
             from . import build as _build
             _build.build()
+        _hip_runtime = _share_torch_hip_runtime()
         lib = C.CDLL(str(LIB_PATH))
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)     # AttributeError here = the library does not match the header
