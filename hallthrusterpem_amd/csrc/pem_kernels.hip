@@ -5,22 +5,23 @@
 //   thruster stage   tests/sim_hallthruster.jl:35-48 (the reference's analytic test double)
 //   plume stage      src/hallmd/models/plume.py:39-140
 //
-// Kernel shape (see DESIGN.md for the measurements behind it).  The path is a streaming map with
-// 120 B in and 752 B out per sample, HBM-write-bound once the per-angle transcendentals are
-// removed, so the design is about (1) few fp64 transcendentals and (2) full-line coalesced stores.
-//   * L lanes share one sample (L = 4 by default); a 64-lane wave owns S = 64/L consecutive
-//     samples.  Lane (s, c) computes angles k = c*CH .. c*CH+CH-1, CH = ceil(91/L).
-//   * The two Gaussians exp(-(k h / a)^2) are advanced along k by the two-term recurrence
-//     e_{k+1} = e_k r_k, r_{k+1} = r_k q  (q = exp(-2 (h/a)^2)), restarted with direct exp() at
-//     every chunk start -- 3 exp per beam per lane instead of 91 per beam per sample; the error
-//     grows as ~CH^2/2 ulp (3e-14 for CH = 23).
-//   * The normaliser D(a) = 2 pi Int_0^{pi/2} exp(-(t/a)^2) sin t dt (identical to the six complex
-//     erfi of plume.py:64-85) is a 24-point Gauss-Legendre sum split over the L lanes of a sample
-//     and combined with wavefront shuffles; below |a| = 0.25 a 10-term series takes over.
-//   * The Simpson sums of plume.py:117-123 are accumulated in the same k loop with folded weights
-//     from an LDS table and combined with the same shuffles.
-//   * A wave's S x 91 profile block is contiguous in j_ion (R = 1), so it is staged in LDS in its
-//     final order and written out with 16-byte-per-lane, 1-KiB-per-instruction stores.
+// Kernel shape (DESIGN.md holds the measurements behind each choice).  The path is a streaming map,
+// 120 B in and 752 B out per sample; the first version was VALU-bound on fp64 transcendentals
+// (1246 VALU instructions per 16 samples), so the design removes them until HBM writes are the bound:
+//   * One 64-lane wave (= one workgroup, persistent over tiles) owns 64 consecutive samples.
+//   * PRELUDE, one lane per sample, nothing redundant: cathode + thruster stages, alpha1/alpha2, the two
+//     normalisers, beam amplitudes.  The normaliser D(a) = 2 pi Int_0^{pi/2} exp(-(t/a)^2) sin t dt
+//     (identical to the six complex erfi of plume.py:64-85) is a degree-11 polynomial in u = 1/a^2 from a
+//     32-interval LDS table (|a| >= 0.25) or a 10-term series (|a| < 0.25) -- no quadrature, no erfi.
+//   * ROUNDS: the wave then walks its 64 samples in L rounds of S = 64/L samples; in a round lane
+//     (s, c) produces angles k = c*CH .. c*CH+CH-1 (CH = ceil(91/L)) of sample s.  The two Gaussians
+//     exp(-(k h / a)^2) advance along k by the two-term recurrence e_{k+1} = e_k r_k, r_{k+1} = r_k q,
+//     and the chunk starts come from the same recurrence at stride CH -- so a sample costs 7 exp in
+//     total (3 per beam + the CEX decay) instead of 182 + 6 erfi.
+//   * The Simpson sums of plume.py:117-123 ride in the same loop (folded weights from an LDS table).
+//   * A round's S x 91 profile block is contiguous in j_ion (R = 1): it is staged in LDS in final order
+//     and leaves as 16-byte-per-lane, 1-KiB-per-instruction stores.
+//   * EPILOGUE, one lane per sample again: cos_div, arccos, T_c, coalesced 512-byte stores.
 //
 // This file is written for gfx950 only: 64-wide waves, 160 KiB LDS, no portability layer.
 #include <hip/hip_runtime.h>
@@ -29,6 +30,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -45,12 +47,10 @@ constexpr double HALF_PI = PEM_PI / 2;
 // |a| beyond which scipy.special.erfi(a/2) overflows in the reference bracket (plume.py:64-85):
 // the reference result is NaN there (found by bisection on the reference; tests/golden plume_edges).
 constexpr double ALPHA_OVERFLOW = 53.28349511409265;
-constexpr double SERIES_BELOW = 0.25;
-constexpr int BLOCK = 256;
-// waves per workgroup of the fast kernel: the LDS tile of one wave is (64/L)*91*8 bytes
-template <int L>
-constexpr int waves_per_block() { return L == 1 ? 2 : 4; }
-constexpr int TABLE_DOUBLES = 2 * NANG + 2 * PEM_NGL;  // {cden,cnum}[91] then {t2,ws}[24]
+constexpr double SERIES_BELOW = 0.25;          // |a| < 0.25  <=>  u = 1/a^2 > 16: series instead of table
+constexpr double GRID_H = HALF_PI / 90.0;      // step of np.linspace(0, pi/2, 91), plume.py:53
+constexpr int BLOCK = 256;                     // elementwise kernels
+constexpr int WAVE = 64;
 
 // ---------------------------------------------------------------------------------------------
 // per-sample scalar stages
@@ -92,30 +92,49 @@ __device__ __forceinline__ ThrusterQoI thruster_stage(double V_a, double V_cc, d
     return o;
 }
 
-// D(a) from a finished Gauss-Legendre sum: series below 0.25, NaN where the reference is NaN.
-__device__ __forceinline__ double finish_normaliser(double a, double gl_sum) {
-    const double a2 = a * a;
-    const double y = 0.5 * a2;
+// exp(x) for x <= 0 without the special-case handling of the library exp: 2^n * P(r), P = degree-13
+// Taylor polynomial on |r| <= ln2/2 (truncation 1.3e-17), n applied with v_ldexp_f64 so that results
+// below the normal range denormalise and then flush to 0 like exp() does.  Arguments below -800 give 0;
+// a NaN argument gives 0 as well -- callers carry NaN through the beam amplitudes instead.
+__device__ __forceinline__ double exp_nonpos(double x) {
+    x = fmax(x, -800.0);
+    const double n = rint(x * 1.4426950408889634074);
+    double r = fma(n, -6.93147180369123816490e-01, x);
+    r = fma(n, -1.90821492927058770002e-10, r);
+    double p = 1.6059043836821614599e-10;  // 1/13!
+    p = fma(p, r, 2.0876756987868098979e-09);
+    p = fma(p, r, 2.5052108385441718775e-08);
+    p = fma(p, r, 2.7557319223985890653e-07);
+    p = fma(p, r, 2.7557319223985890653e-06);
+    p = fma(p, r, 2.4801587301587301587e-05);
+    p = fma(p, r, 1.9841269841269841270e-04);
+    p = fma(p, r, 1.3888888888888888889e-03);
+    p = fma(p, r, 8.3333333333333333333e-03);
+    p = fma(p, r, 4.1666666666666666667e-02);
+    p = fma(p, r, 1.6666666666666666667e-01);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
+
+// D(a) with u = 1/a^2: polynomial table for |a| >= 0.25, series below, NaN where the reference is NaN.
+// `poly` points at the 32 x 12 coefficient table (LDS in the fast kernel, global memory otherwise).
+__device__ __forceinline__ double normaliser(double a, double u, const double* poly) {
+    int i = (int)(2.0 * u);  // u >= 0; NaN -> 0, +inf saturates
+    i = i < 0 ? 0 : (i > PEM_NDI - 1 ? PEM_NDI - 1 : i);
+    const double x = fma(4.0, u, -(double)(2 * i + 1));
+    const double* c = poly + i * PEM_NDC;
+    double d = c[PEM_NDC - 1];
+#pragma unroll
+    for (int j = PEM_NDC - 2; j >= 0; --j) d = fma(d, x, c[j]);
+    const double a2 = a * a, y = 0.5 * a2;
     double s = PEM_DAWSON[PEM_NDAW - 1];
 #pragma unroll
-    for (int i = PEM_NDAW - 2; i >= 0; --i) s = fma(s, y, PEM_DAWSON[i]);
-    double D = (fabs(a) < SERIES_BELOW) ? PEM_PI * a2 * s : gl_sum;
+    for (int j = PEM_NDAW - 2; j >= 0; --j) s = fma(s, y, PEM_DAWSON[j]);
+    double D = (fabs(a) < SERIES_BELOW) ? PEM_PI * a2 * s : d;
     if (!(fabs(a) <= ALPHA_OVERFLOW) || a == 0.0) D = __builtin_nan("");
     return D;
-}
-
-template <int MASK_LO>
-__device__ __forceinline__ double xor_reduce_add(double v) {
-#pragma unroll
-    for (int m = MASK_LO; m < 64; m <<= 1) v += __shfl_xor(v, m);
-    return v;
-}
-
-template <int MASK_LO>
-__device__ __forceinline__ int xor_reduce_or(int v) {
-#pragma unroll
-    for (int m = MASK_LO; m < 64; m <<= 1) v |= __shfl_xor(v, m);
-    return v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -135,156 +154,285 @@ struct CoupledIO {
     double *V_cc, *I_B0, *T;
 };
 
+// the per-sample inputs of one lane, prefetched one tile ahead
+template <bool COUPLED>
+struct SampleIn {
+    double P_b, c0, c1, c2, c3, c4, c5, sigma;
+    double x0, x1, x2, x3, x4, x5, x6;  // COUPLED: V_a T_e V_vac Pstar P_T mdot_a a_1 ; else I_B0, T, unused
+};
+
+template <bool COUPLED>
+__device__ __forceinline__ SampleIn<COUPLED> load_sample(const PlumeIO& io, const CoupledIO& cio, long long gi) {
+    SampleIn<COUPLED> v;
+    v.P_b = io.P_b[gi];
+    v.c0 = io.c0[gi];
+    v.c1 = io.c1[gi];
+    v.c2 = io.c2[gi];
+    v.c3 = io.c3[gi];
+    v.c4 = io.c4[gi];
+    v.c5 = io.c5[gi];
+    v.sigma = io.sigma[gi];
+    if constexpr (COUPLED) {
+        v.x0 = cio.V_a[gi];
+        v.x1 = cio.T_e[gi];
+        v.x2 = cio.V_vac[gi];
+        v.x3 = cio.Pstar[gi];
+        v.x4 = cio.P_T[gi];
+        v.x5 = cio.mdot_a[gi];
+        v.x6 = cio.a_1[gi];
+    } else {
+        v.x0 = io.I_B0[gi];
+        v.x1 = io.T ? io.T[gi] : 0.0;
+        v.x2 = v.x3 = v.x4 = v.x5 = v.x6 = 0.0;
+    }
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------------
-// fast path: R = 1, L lanes per sample, LDS-staged coalesced profile stores
-//   COUPLED: cathode + thruster stages are evaluated in front of the plume (inputs from CoupledIO)
-//   WRITE_J: stage and store the 91-point profile (false = reduced-QoI mode)
+// fast path: R = 1.  One wave per workgroup, persistent over 64-sample tiles.
+//   L        lanes that share a sample during the rounds (2, 4 or 8)
+//   COUPLED  cathode + thruster stages are evaluated in front of the plume (inputs from CoupledIO)
+//   WRITE_J  stage and store the 91-point profile (false = reduced-QoI mode)
+// LDS map (doubles): simpson[96][2] | dpoly[32*12] | params[9][64] | partial[64*L][2] | tile[S*91] | 2 (sink)
+// The Simpson table is padded with zero weights to L*CH <= 96 entries so the angle loop needs no branch.
 // ---------------------------------------------------------------------------------------------
-template <int L, bool COUPLED, bool WRITE_J>
-__global__ __launch_bounds__(64 * waves_per_block<L>()) void plume_r1_kernel(PlumeIO io, CoupledIO cio) {
-    static_assert(L == 1 || L == 2 || L == 4 || L == 8, "lanes per sample");
-    constexpr int WAVES = waves_per_block<L>();
-    constexpr int NTHREADS = 64 * WAVES;
-    constexpr int S = 64 / L;               // samples per wave
+constexpr int NPARAM = 9;   // X1 X2 jcex | r0 G E (beam 1) | r0 G E (beam 2)
+constexpr int NSIMP = 96;   // >= L*CH for L in {2, 4, 8}
+template <int L, bool WRITE_J>
+constexpr int fast_lds_doubles() {
+    return 2 * NSIMP + PEM_NDI * PEM_NDC + NPARAM * WAVE + 2 * WAVE * L + (WRITE_J ? (WAVE / L) * NANG + 2 : 0);
+}
+
+// Order LDS traffic inside ONE wave (the workgroup is a single wave): the LDS unit executes a wave's
+// DS instructions in issue order, so only the compiler has to be kept from reordering them.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// LDS views of one wave
+struct WaveLds {
+    const double2* simpson;  // [96] {cden, cnum}
+    const double* poly;      // [32*12]
+    double* params;          // [9][64]
+    double2* partial;        // [64*L] {den, num}
+    double* tile;            // [S*91] + 2
+};
+
+// One 64-sample tile.  FULL = every sample of the tile exists (the steady state of the persistent loop:
+// no bounds checks and a fixed number of stores, so the compiler can count them); FULL = false is the
+// ragged last tile of a batch.
+template <int L, bool COUPLED, bool WRITE_J, bool FULL>
+__device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO& cio, const WaveLds& m,
+                                             const SampleIn<COUPLED>& in, long long t, int lane, double rad,
+                                             double inv_r2, double inv_2pi_r2) {
+    constexpr int S = WAVE / L;             // samples per round
     constexpr int CH = (NANG + L - 1) / L;  // angles per lane
-    constexpr int NPL = PEM_NGL / L;        // Gauss-Legendre nodes per lane
-    constexpr int TILE = S * NANG;          // doubles per wave tile
-    constexpr int UNROLL = CH <= 23 ? CH : 2;
+    constexpr int TILE = S * NANG;          // doubles per round tile
+    constexpr int PAIRS = TILE / 2;         // 16-byte pieces of a full round tile (TILE is even)
+    const int s = lane % S, c = lane / S;   // role during the rounds
+    const int k0 = c * CH;
+    const double2* my_w = m.simpson + k0;   // this lane's folded Simpson weights
+    double* params = m.params;
+    double* tile = m.tile;
+    const long long g = t * WAVE + lane;
+    const bool live = FULL || g < io.n;
 
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double* tab = reinterpret_cast<double*>(smem_raw);
-    double2* tab_simpson = reinterpret_cast<double2*>(tab);            // [91] {cden, cnum}
-    double2* tab_gl = reinterpret_cast<double2*>(tab + 2 * NANG);      // [24] {t2, ws}
-    double* tiles = tab + TABLE_DOUBLES;
-
-    const int tid = threadIdx.x;
-    for (int i = tid; i < NANG; i += NTHREADS) tab_simpson[i] = make_double2(PEM_SIMPSON_CDEN[i], PEM_SIMPSON_CNUM[i]);
-    if (tid < PEM_NGL) tab_gl[tid] = make_double2(PEM_GL_T2[tid], PEM_GL_WS[tid]);
-    __syncthreads();
-
-    const int wave = tid >> 6, lane = tid & 63;
-    const int s = lane % S, c = lane / S;
-    const long long tile_base = ((long long)blockIdx.x * WAVES + wave) * S;  // first sample of this wave
-    const long long g = tile_base + s;
-    const bool live = g < io.n;
-    const long long gi = live ? g : io.n - 1;  // dead lanes recompute the last sample, write nothing
-
-    // ---- inputs (SoA: S consecutive doubles per array per wave, L lanes share an address) ----
-    const double P_b = io.P_b[gi];
-    const double c0 = io.c0[gi], c1 = io.c1[gi], c2 = io.c2[gi], c3 = io.c3[gi];
-    const double c4 = io.c4[gi], c5 = io.c5[gi], sigma = io.sigma[gi];
+    // ------------------------------ PRELUDE: one lane per sample ------------------------------
     double I_B0, thrust = 0.0, V_cc = 0.0;
     bool have_T;
     if constexpr (COUPLED) {
-        const double V_a = cio.V_a[gi];
-        V_cc = cathode_vcc(P_b, V_a, cio.T_e[gi], cio.V_vac[gi], cio.Pstar[gi], cio.P_T[gi], io.torr2pa);
-        const ThrusterQoI th = thruster_stage(V_a, V_cc, cio.mdot_a[gi], cio.a_1[gi]);
+        V_cc = cathode_vcc(in.P_b, in.x0, in.x1, in.x2, in.x3, in.x4, io.torr2pa);
+        const ThrusterQoI th = thruster_stage(in.x0, V_cc, in.x5, in.x6);
         I_B0 = th.I_B0;
         thrust = th.T;
         have_T = true;
     } else {
-        I_B0 = io.I_B0[gi];
+        I_B0 = in.x0;
+        thrust = in.x1;
         have_T = io.T != nullptr;
-        if (have_T) thrust = io.T[gi];
     }
-
-    // ---- plume.py:40-61 ----
-    const double P_B = P_b * io.torr2pa;
-    const double n_neutral = c4 * P_B + c5;
-    double a1 = c2 * P_B + c3;
+    // plume.py:40-61
+    const double P_B = in.P_b * io.torr2pa;
+    const double n_neutral = in.c4 * P_B + in.c5;
+    double a1 = in.c2 * P_B + in.c3;
     if (a1 > HALF_PI) a1 = HALF_PI;
-    const double a2 = a1 / c1;
+    const double a2 = a1 / in.c1;
     const double u1 = 1.0 / (a1 * a1), u2 = 1.0 / (a2 * a2);
+    const double A1 = (1.0 - in.c0) / normaliser(a1, u1, m.poly);  // plume.py:64-73
+    const double A2 = in.c0 / normaliser(a2, u2, m.poly);          // plume.py:75-85
+    // plume.py:95-100 at the single radius
+    const double decay = exp(-rad * n_neutral * in.sigma);
+    const double j_cex = I_B0 * (1.0 - decay) * inv_2pi_r2;
+    const double base = I_B0 * decay * inv_r2;
+    // Gaussian recurrences: e_k = exp(-k^2 s), s = (h/a)^2; chunk starts at k = c*CH
+    const double s1 = (GRID_H * GRID_H) * u1, s2 = (GRID_H * GRID_H) * u2;
+    // a1 == 0: exp(-(0/0)^2) is NaN in the reference; the amplitudes carry it (A1 is NaN there)
+    params[0 * WAVE + lane] = base * A1;
+    params[1 * WAVE + lane] = base * A2;
+    params[2 * WAVE + lane] = j_cex;
+    params[3 * WAVE + lane] = exp_nonpos(-s1);
+    params[4 * WAVE + lane] = exp_nonpos(-(2.0 * CH) * s1);
+    params[5 * WAVE + lane] = exp_nonpos(-(double)(CH * CH) * s1);
+    params[6 * WAVE + lane] = exp_nonpos(-s2);
+    params[7 * WAVE + lane] = exp_nonpos(-(2.0 * CH) * s2);
+    params[8 * WAVE + lane] = exp_nonpos(-(double)(CH * CH) * s2);
+    const unsigned long long a1_nonpos = __ballot(a1 <= 0.0);  // plume.py:105, first term
+    unsigned long long inv_mask = 0;
+    wave_lds_sync();
 
-    // ---- normalisers: this lane's share of the 24 Gauss-Legendre nodes, then shuffle-reduce ----
-    double gl1 = 0.0, gl2 = 0.0;
+    // ------------------------------ ROUNDS: L lanes per sample ------------------------------
 #pragma unroll
-    for (int m = 0; m < NPL; ++m) {
-        const double2 node = tab_gl[c + L * m];
-        gl1 = fma(node.y, exp(-node.x * u1), gl1);
-        gl2 = fma(node.y, exp(-node.x * u2), gl2);
-    }
-    if constexpr (L > 1) {
-        gl1 = xor_reduce_add<S>(gl1);
-        gl2 = xor_reduce_add<S>(gl2);
-    }
-    const double A1 = (1.0 - c0) / finish_normaliser(a1, gl1);  // plume.py:64-73
-    const double A2 = c0 / finish_normaliser(a2, gl2);          // plume.py:75-85
-
-    // ---- plume.py:95-100 at the single radius ----
-    const double rad = io.radius;
-    const double decay = exp(-rad * n_neutral * sigma);
-    const double j_cex = I_B0 * (1.0 - decay) / (2.0 * PEM_PI * (rad * rad));
-    const double base = I_B0 * decay / (rad * rad);
-    const double B1 = base * A1, B2 = base * A2;
-
-    // ---- Gaussian recurrences, started exactly at this lane's first angle ----
-    constexpr double H = HALF_PI / 90.0;  // grid step of np.linspace(0, pi/2, 91)
-    const double s1 = (H * H) * u1, s2 = (H * H) * u2;
-    const int k0 = c * CH;
-    const double dk0 = (double)k0;
-    double e1 = exp(-(dk0 * dk0) * s1), r1 = exp(-(2.0 * dk0 + 1.0) * s1);
-    double e2 = exp(-(dk0 * dk0) * s2), r2 = exp(-(2.0 * dk0 + 1.0) * s2);
-    const double q1 = exp(-2.0 * s1), q2 = exp(-2.0 * s2);
-
-    double* tile = tiles + wave * TILE;
-    double den = 0.0, num = 0.0;
-    int invalid = (a1 <= 0.0) ? 1 : 0;  // plume.py:105, first term
-#pragma unroll UNROLL
-    for (int j = 0; j < CH; ++j) {
-        const int k = k0 + j;
-        if (L == 1 || k < NANG) {
-            const double2 w = tab_simpson[k];
-            const double f = B1 * e1 + B2 * e2;  // j_beam + j_scat
-            const double ji = f + j_cex;         // plume.py:102
-            if constexpr (WRITE_J) tile[s * NANG + k] = ji;
-            invalid |= (ji <= 0.0) ? 1 : 0;      // plume.py:105, second term
-            den = fma(w.x, f, den);
-            num = fma(w.y, f, num);
-            e1 *= r1;
-            r1 *= q1;
-            e2 *= r2;
-            r2 *= q2;
+    for (int round = 0; round < L; ++round) {
+        const int smp = round * S + s;
+        double X1 = params[0 * WAVE + smp], X2 = params[1 * WAVE + smp];
+        const double jcex = params[2 * WAVE + smp];
+        const double r01 = params[3 * WAVE + smp], G1 = params[4 * WAVE + smp], E1 = params[5 * WAVE + smp];
+        const double r02 = params[6 * WAVE + smp], G2 = params[7 * WAVE + smp], E2 = params[8 * WAVE + smp];
+        // coarse recurrence to this lane's first angle k0 = c*CH:
+        //   e_{k0} = E^(c^2), r_{k0} = exp(-(2 k0 + 1) s) = r0 * G^c
+        double rr1 = r01, rr2 = r02, rho1 = E1, rho2 = E2;
+        const double E1sq = E1 * E1, E2sq = E2 * E2;
+#pragma unroll
+        for (int i = 0; i < L - 1; ++i) {
+            if (i < c) {
+                X1 *= rho1;
+                rho1 *= E1sq;
+                rr1 *= G1;
+                X2 *= rho2;
+                rho2 *= E2sq;
+                rr2 *= G2;
+            }
+        }
+        const double q1 = r01 * r01, q2 = r02 * r02;
+        double den = 0.0, num = 0.0, lo = __builtin_inf();
+        // The weight reads are issued PF iterations ahead IN SOURCE ORDER: the tile stores in between are
+        // LDS stores the compiler must assume may alias the table, so it cannot hoist the reads itself.
+        constexpr int PF = 6;
+        double2 wq[CH];
+#pragma unroll
+        for (int j = 0; j < PF && j < CH; ++j) wq[j] = my_w[j];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            if (j + PF < CH) wq[j + PF] = my_w[j + PF];
+            const double f = X1 + X2;     // j_beam + j_scat
+            const double ji = f + jcex;   // plume.py:102
+            if ((L - 1) * CH + j < NANG) {  // an angle every chunk has (compile-time after unrolling)
+                if constexpr (WRITE_J) tile[s * NANG + k0 + j] = ji;
+                lo = fmin(lo, ji);
+            } else {                        // past 90 degrees in the last chunk: store to the sink, skip the min
+                const bool in_range = k0 + j < NANG;
+                if constexpr (WRITE_J) tile[in_range ? s * NANG + k0 + j : TILE] = ji;
+                lo = fmin(lo, in_range ? ji : __builtin_inf());
+            }
+            den = fma(wq[j].x, f, den);
+            num = fma(wq[j].y, f, num);
+            X1 *= rr1;
+            rr1 *= q1;
+            X2 *= rr2;
+            rr2 *= q2;
+        }
+        m.partial[smp * L + c] = make_double2(den, num);
+        // plume.py:105: invalid if alpha1 <= 0 or any j_ion <= 0 (NaN compares false)
+        unsigned long long bad = __ballot(lo <= 0.0);
+#pragma unroll
+        for (int sh = S; sh < WAVE; sh <<= 1) bad |= bad >> sh;   // fold the L chunk lanes of a sample onto bit s
+        bad = (bad | (a1_nonpos >> (round * S))) & ((S == 64) ? ~0ull : ((1ull << S) - 1));
+        inv_mask |= bad << (round * S);
+        if constexpr (WRITE_J) {
+            if ((bad >> s) & 1) {  // plume.py:106: the whole profile of an invalid sample becomes 1e-20 (rare)
+                for (int j = 0; j < CH; ++j)
+                    if (k0 + j < NANG) tile[s * NANG + k0 + j] = 1e-20;
+            }
+            wave_lds_sync();
+            // the round's S*91 doubles are one contiguous, 16-byte aligned block of j_ion
+            const long long first = t * WAVE + (long long)round * S;
+            const double2* src2 = reinterpret_cast<const double2*>(tile);
+            if constexpr (FULL) {
+                double2* dst2 = reinterpret_cast<double2*>(io.j_ion + first * NANG);
+#pragma unroll
+                for (int it = 0; it < PAIRS / WAVE; ++it) dst2[it * WAVE + lane] = src2[it * WAVE + lane];
+                if (PAIRS % WAVE != 0 && lane < PAIRS % WAVE)
+                    dst2[(PAIRS / WAVE) * WAVE + lane] = src2[(PAIRS / WAVE) * WAVE + lane];
+            } else {
+                long long valid = (io.n - first) * NANG;   // doubles of this round that exist
+                if (valid > TILE) valid = TILE;
+                if (valid > 0) {
+                    double* dst = io.j_ion + first * NANG;
+                    double2* dst2 = reinterpret_cast<double2*>(dst);
+                    const int pairs = (int)(valid >> 1);
+                    for (int i = lane; i < pairs; i += WAVE) dst2[i] = src2[i];
+                    if ((valid & 1) && lane == 0) dst[valid - 1] = tile[valid - 1];
+                }
+            }
+            wave_lds_sync();
         }
     }
-    if constexpr (L > 1) {
-        den = xor_reduce_add<S>(den);
-        num = xor_reduce_add<S>(num);
-        invalid = xor_reduce_or<S>(invalid);
-    }
+    wave_lds_sync();
 
-    // ---- plume.py:124-140 ----
-    double cos_div = num / den;
+    // ------------------------------ EPILOGUE: one lane per sample ------------------------------
+    double den = 0.0, num = 0.0;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        const double2 p = m.partial[lane * L + i];
+        den += p.x;
+        num += p.y;
+    }
+    double cos_div = num / den;  // plume.py:124-127
     if (cos_div == __builtin_inf()) cos_div = __builtin_nan("");
-    if (live && c == 0) {
+    if (live) {
         io.div[g] = acos(cos_div);
         if (have_T) io.Tc[g] = thrust * cos_div;
-        if (io.invalid) io.invalid[g] = (uint8_t)invalid;
+        if (io.invalid) io.invalid[g] = (uint8_t)((inv_mask >> lane) & 1);
         if constexpr (COUPLED) {
             cio.V_cc[g] = V_cc;
             if (cio.I_B0) cio.I_B0[g] = I_B0;
             if (cio.T) cio.T[g] = thrust;
         }
     }
+    wave_lds_sync();  // params / partial are rewritten by the next tile
+}
 
-    if constexpr (WRITE_J) {
-        if (invalid) {  // plume.py:106: the whole profile of an invalid sample becomes 1e-20 (rare)
-            for (int j = 0; j < CH; ++j)
-                if (k0 + j < NANG) tile[s * NANG + k0 + j] = 1e-20;
+template <int L, bool COUPLED, bool WRITE_J>
+__global__ __launch_bounds__(WAVE) void plume_r1_kernel(PlumeIO io, CoupledIO cio, long long ntiles) {
+    static_assert(L == 2 || L == 4 || L == 8, "lanes per sample");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* lds = reinterpret_cast<double*>(smem_raw);
+    double2* tab_simpson = reinterpret_cast<double2*>(lds);          // [96] {cden, cnum}, zero past angle 90
+    double* tab_poly = lds + 2 * NSIMP;                               // [32*12]
+    WaveLds m;
+    m.simpson = tab_simpson;
+    m.poly = tab_poly;
+    m.params = tab_poly + PEM_NDI * PEM_NDC;                          // [9][64]
+    m.partial = reinterpret_cast<double2*>(m.params + NPARAM * WAVE); // [64*L]
+    m.tile = m.params + NPARAM * WAVE + 2 * WAVE * L;                 // [S*91] + 2
+
+    const int lane = threadIdx.x;
+    for (int i = lane; i < NSIMP; i += WAVE)
+        tab_simpson[i] = i < NANG ? make_double2(PEM_SIMPSON_CDEN[i], PEM_SIMPSON_CNUM[i]) : make_double2(0.0, 0.0);
+    for (int i = lane; i < PEM_NDI * PEM_NDC; i += WAVE) tab_poly[i] = PEM_DPOLY[i];
+    wave_lds_sync();
+
+    const double rad = io.radius;
+    const double inv_r2 = 1.0 / (rad * rad);
+    const double inv_2pi_r2 = 1.0 / (2.0 * PEM_PI * (rad * rad));
+
+    // persistent loop over the tiles whose 64 samples all exist; inputs are prefetched one tile ahead
+    const long long nfull = io.n / WAVE;
+    long long t = blockIdx.x;
+    if (t < nfull) {
+        SampleIn<COUPLED> nxt = load_sample<COUPLED>(io, cio, t * WAVE + lane);
+        for (; t < nfull; t += gridDim.x) {
+            const SampleIn<COUPLED> in = nxt;
+            if (t + gridDim.x < nfull) nxt = load_sample<COUPLED>(io, cio, (t + gridDim.x) * WAVE + lane);
+            process_tile<L, COUPLED, WRITE_J, true>(io, cio, m, in, t, lane, rad, inv_r2, inv_2pi_r2);
         }
-        __syncthreads();
-        // the wave's S*91 doubles are one contiguous, 16-byte aligned block of j_ion
-        long long valid = (io.n - tile_base) * NANG;  // doubles of this tile that exist
-        if (valid > TILE) valid = TILE;
-        if (valid > 0) {
-            double* dst = io.j_ion + tile_base * NANG;
-            const double2* src2 = reinterpret_cast<const double2*>(tile);
-            double2* dst2 = reinterpret_cast<double2*>(dst);
-            const int pairs = (int)(valid >> 1);
-#pragma unroll 4
-            for (int i = lane; i < pairs; i += 64) dst2[i] = src2[i];
-            if ((valid & 1) && lane == 0) dst[valid - 1] = tile[valid - 1];
-        }
+    }
+    // the ragged last tile (n % 64 samples) goes to the wave that would have been next in line for it
+    if (nfull < ntiles && (nfull % gridDim.x) == blockIdx.x) {
+        const long long g = nfull * WAVE + lane;
+        const SampleIn<COUPLED> in = load_sample<COUPLED>(io, cio, g < io.n ? g : io.n - 1);
+        process_tile<L, COUPLED, WRITE_J, false>(io, cio, m, in, nfull, lane, rad, inv_r2, inv_2pi_r2);
     }
 }
 
@@ -303,13 +451,8 @@ __global__ __launch_bounds__(BLOCK) void plume_generic_kernel(PlumeIO io, const 
     if (a1 > HALF_PI) a1 = HALF_PI;
     const double a2 = a1 / c1;
     const double u1 = 1.0 / (a1 * a1), u2 = 1.0 / (a2 * a2);
-    double gl1 = 0.0, gl2 = 0.0;
-    for (int i = 0; i < PEM_NGL; ++i) {
-        gl1 = fma(PEM_GL_WS[i], exp(-PEM_GL_T2[i] * u1), gl1);
-        gl2 = fma(PEM_GL_WS[i], exp(-PEM_GL_T2[i] * u2), gl2);
-    }
-    const double A1 = (1.0 - c0) / finish_normaliser(a1, gl1);
-    const double A2 = c0 / finish_normaliser(a2, gl2);
+    const double A1 = (1.0 - c0) / normaliser(a1, u1, PEM_DPOLY);
+    const double A2 = c0 / normaliser(a2, u2, PEM_DPOLY);
     constexpr double H = HALF_PI / 90.0;
     const double s1 = (H * H) * u1, s2 = (H * H) * u2;
     const double r10 = exp(-s1), r20 = exp(-s2), q1 = exp(-2.0 * s1), q2 = exp(-2.0 * s2);
@@ -419,21 +562,34 @@ int check_device() {
     return PEM_OK;
 }
 
+// persistent grid of the fast kernel: as many single-wave workgroups as the LDS admits on every CU
+int fast_grid(size_t lds_bytes, long long ntiles, unsigned* grid) {
+    static int cus[64] = {0};
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(PEM_ERR_INVALID_ARG, "device index %d out of range", dev);
+    if (cus[dev] == 0) HIP_TRY(hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev));
+    long long per_cu = (long long)(160 * 1024 / lds_bytes);
+    if (per_cu > 16) per_cu = 16;
+    if (const char* e = getenv("PEM_WAVES_PER_CU")) {   // tuning/experiments only
+        const long long v = atoll(e);
+        if (v >= 1 && v < per_cu) per_cu = v;
+    }
+    if (per_cu < 1) per_cu = 1;
+    long long g = (long long)cus[dev] * per_cu;
+    if (g > ntiles) g = ntiles;
+    *grid = (unsigned)g;
+    return PEM_OK;
+}
+
 template <int L, bool COUPLED, bool WRITE_J>
 int launch_r1(const PlumeIO& io, const CoupledIO& cio, hipStream_t st) {
-    constexpr int S = 64 / L;
-    constexpr int WAVES = waves_per_block<L>();
-    const size_t lds = (size_t)TABLE_DOUBLES * 8 + (WRITE_J ? (size_t)WAVES * S * NANG * 8 : 0);
-    const long long per_block = (long long)WAVES * S;
-    const long long blocks = (io.n + per_block - 1) / per_block;
-    if (blocks > 0x7fffffffLL) return fail(PEM_ERR_INVALID_ARG, "n = %lld needs more than 2^31 workgroups", io.n);
+    const size_t lds = (size_t)fast_lds_doubles<L, WRITE_J>() * 8;
+    const long long ntiles = (io.n + WAVE - 1) / WAVE;
+    unsigned grid = 0;
+    if (int rc = fast_grid(lds, ntiles, &grid)) return rc;
     auto kern = plume_r1_kernel<L, COUPLED, WRITE_J>;
-    if (lds > 48 * 1024) {  // opt in to more than the default dynamic-LDS limit, once per instantiation
-        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        HIP_TRY(attr);
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * WAVES), lds, st, io, cio);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), lds, st, io, cio, ntiles);
     HIP_TRY(hipGetLastError());
     return PEM_OK;
 }
@@ -441,7 +597,6 @@ int launch_r1(const PlumeIO& io, const CoupledIO& cio, hipStream_t st) {
 template <bool COUPLED, bool WRITE_J>
 int dispatch_lanes(const PlumeIO& io, const CoupledIO& cio, hipStream_t st) {
     switch (g_lanes) {
-        case 1: return launch_r1<1, COUPLED, WRITE_J>(io, cio, st);
         case 2: return launch_r1<2, COUPLED, WRITE_J>(io, cio, st);
         case 8: return launch_r1<8, COUPLED, WRITE_J>(io, cio, st);
         default: return launch_r1<4, COUPLED, WRITE_J>(io, cio, st);
@@ -520,7 +675,7 @@ int pem_synchronize(pem_stream_t stream) {
 
 int pem_set_lanes_per_sample(int lanes) {
     if (lanes == 0) lanes = 4;
-    if (lanes == 1 || lanes == 2 || lanes == 4 || lanes == 8) g_lanes = lanes;
+    if (lanes == 2 || lanes == 4 || lanes == 8) g_lanes = lanes;
     return g_lanes;
 }
 

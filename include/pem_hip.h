@@ -59,7 +59,7 @@ const char* pem_last_error(void);
 int pem_device_count(void);                 /* number of HIP devices, 0 if none / no driver        */
 int pem_init(int device);                   /* hipSetDevice(device) + upload the constant tables   */
 int pem_synchronize(pem_stream_t stream);   /* hipStreamSynchronize                                */
-/* Tuning knob of the plume/coupled kernels: lanes that share one sample (1, 2, 4, 8 or 16).
+/* Tuning knob of the plume/coupled kernels: lanes that share one sample (2, 4 or 8).
  * 0 restores the default.  Returns the value in effect. */
 int pem_set_lanes_per_sample(int lanes);
 /* The 91-point angle grid (host memory, valid for the life of the library): j_ion_coords.    */

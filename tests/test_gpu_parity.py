@@ -116,7 +116,7 @@ def test_cathode_config1_lhs(pem, oc):
     assert rel_err(got, want) <= RTOL
 
 
-@pytest.mark.parametrize('lanes', [1, 2, 4, 8])
+@pytest.mark.parametrize('lanes', [2, 4, 8])
 @pytest.mark.parametrize('n', [1, 63, 65, 1000, 4099])
 def test_plume_vs_oracle_every_variant_ragged(pem, oc, lanes, n):
     from hallthrusterpem_amd import _lib
