@@ -161,28 +161,45 @@ struct SampleIn {
     double x0, x1, x2, x3, x4, x5, x6;  // COUPLED: V_a T_e V_vac Pstar P_T mdot_a a_1 ; else I_B0, T, unused
 };
 
+// read-once input stream
+__device__ __forceinline__ double stream_load(const double* p) {
+#if defined(PEM_NT_LOADS) && PEM_NT_LOADS
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+
+__device__ __forceinline__ void stream_store1(double v, double* p) {
+#if defined(PEM_NT_QOI) && PEM_NT_QOI
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 template <bool COUPLED>
 __device__ __forceinline__ SampleIn<COUPLED> load_sample(const PlumeIO& io, const CoupledIO& cio, long long gi) {
     SampleIn<COUPLED> v;
-    v.P_b = io.P_b[gi];
-    v.c0 = io.c0[gi];
-    v.c1 = io.c1[gi];
-    v.c2 = io.c2[gi];
-    v.c3 = io.c3[gi];
-    v.c4 = io.c4[gi];
-    v.c5 = io.c5[gi];
-    v.sigma = io.sigma[gi];
+    v.P_b = stream_load(io.P_b + gi);
+    v.c0 = stream_load(io.c0 + gi);
+    v.c1 = stream_load(io.c1 + gi);
+    v.c2 = stream_load(io.c2 + gi);
+    v.c3 = stream_load(io.c3 + gi);
+    v.c4 = stream_load(io.c4 + gi);
+    v.c5 = stream_load(io.c5 + gi);
+    v.sigma = stream_load(io.sigma + gi);
     if constexpr (COUPLED) {
-        v.x0 = cio.V_a[gi];
-        v.x1 = cio.T_e[gi];
-        v.x2 = cio.V_vac[gi];
-        v.x3 = cio.Pstar[gi];
-        v.x4 = cio.P_T[gi];
-        v.x5 = cio.mdot_a[gi];
-        v.x6 = cio.a_1[gi];
+        v.x0 = stream_load(cio.V_a + gi);
+        v.x1 = stream_load(cio.T_e + gi);
+        v.x2 = stream_load(cio.V_vac + gi);
+        v.x3 = stream_load(cio.Pstar + gi);
+        v.x4 = stream_load(cio.P_T + gi);
+        v.x5 = stream_load(cio.mdot_a + gi);
+        v.x6 = stream_load(cio.a_1 + gi);
     } else {
-        v.x0 = io.I_B0[gi];
-        v.x1 = io.T ? io.T[gi] : 0.0;
+        v.x0 = stream_load(io.I_B0 + gi);
+        v.x1 = io.T ? stream_load(io.T + gi) : 0.0;
         v.x2 = v.x3 = v.x4 = v.x5 = v.x6 = 0.0;
     }
     return v;
@@ -208,6 +225,22 @@ constexpr int fast_lds_doubles() {
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+}
+
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+// 16-byte store of the write-once profile stream.  Non-temporal: measured 227.6 -> 190.7 us per 1.25e6-sample
+// launch against plain stores, interleaved A/B (tools/ab_bench.py); the same hint on the small input
+// loads or on the per-sample QoI stores is slower and is not used.
+#ifndef PEM_NT_STORES
+#define PEM_NT_STORES 1
+#endif
+__device__ __forceinline__ void stream_store(f64x2 v, f64x2* dst) {
+#if PEM_NT_STORES
+    __builtin_nontemporal_store(v, dst);
+#else
+    *dst = v;
+#endif
 }
 
 // LDS views of one wave
@@ -349,11 +382,12 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
             const long long first = t * WAVE + (long long)round * S;
             const double2* src2 = reinterpret_cast<const double2*>(tile);
             if constexpr (FULL) {
-                double2* dst2 = reinterpret_cast<double2*>(io.j_ion + first * NANG);
+                f64x2* dst2 = reinterpret_cast<f64x2*>(io.j_ion + first * NANG);
+                const f64x2* srcv = reinterpret_cast<const f64x2*>(tile);
 #pragma unroll
-                for (int it = 0; it < PAIRS / WAVE; ++it) dst2[it * WAVE + lane] = src2[it * WAVE + lane];
+                for (int it = 0; it < PAIRS / WAVE; ++it) stream_store(srcv[it * WAVE + lane], &dst2[it * WAVE + lane]);
                 if (PAIRS % WAVE != 0 && lane < PAIRS % WAVE)
-                    dst2[(PAIRS / WAVE) * WAVE + lane] = src2[(PAIRS / WAVE) * WAVE + lane];
+                    stream_store(srcv[(PAIRS / WAVE) * WAVE + lane], &dst2[(PAIRS / WAVE) * WAVE + lane]);
             } else {
                 long long valid = (io.n - first) * NANG;   // doubles of this round that exist
                 if (valid > TILE) valid = TILE;
@@ -381,13 +415,13 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
     double cos_div = num / den;  // plume.py:124-127
     if (cos_div == __builtin_inf()) cos_div = __builtin_nan("");
     if (live) {
-        io.div[g] = acos(cos_div);
-        if (have_T) io.Tc[g] = thrust * cos_div;
+        stream_store1(acos(cos_div), io.div + g);
+        if (have_T) stream_store1(thrust * cos_div, io.Tc + g);
         if (io.invalid) io.invalid[g] = (uint8_t)((inv_mask >> lane) & 1);
         if constexpr (COUPLED) {
-            cio.V_cc[g] = V_cc;
-            if (cio.I_B0) cio.I_B0[g] = I_B0;
-            if (cio.T) cio.T[g] = thrust;
+            stream_store1(V_cc, cio.V_cc + g);
+            if (cio.I_B0) stream_store1(I_B0, cio.I_B0 + g);
+            if (cio.T) stream_store1(thrust, cio.T + g);
         }
     }
     wave_lds_sync();  // params / partial are rewritten by the next tile
@@ -569,8 +603,11 @@ int fast_grid(size_t lds_bytes, long long ntiles, unsigned* grid) {
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return fail(PEM_ERR_INVALID_ARG, "device index %d out of range", dev);
     if (cus[dev] == 0) HIP_TRY(hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev));
+    // One wave per SIMD (4 per CU) is the measured optimum; a count that leaves the four SIMDs of a CU
+    // unevenly loaded (5 or 6 waves) is 8-10 % slower than 4 (tools/ab_bench.py sweep).
     long long per_cu = (long long)(160 * 1024 / lds_bytes);
-    if (per_cu > 16) per_cu = 16;
+    if (per_cu > 4) per_cu = 4 * (per_cu / 4);
+    if (per_cu > 4) per_cu = 4;
     if (const char* e = getenv("PEM_WAVES_PER_CU")) {   // tuning/experiments only
         const long long v = atoll(e);
         if (v >= 1 && v < per_cu) per_cu = v;

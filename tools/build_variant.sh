@@ -1,0 +1,10 @@
+#!/bin/bash
+# Build an experimental variant of libpem_hip.so: tools/build_variant.sh <name> [-DMACRO=1 ...]
+# -> build_variants/libpem_<name>.so (git-ignored, but it travels to the GPU box with gpurun)
+set -e
+cd "$(dirname "$0")/.."
+name=$1; shift
+mkdir -p build_variants
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Iinclude -Ihallthrusterpem_amd/csrc "$@" \
+    hallthrusterpem_amd/csrc/pem_kernels.hip -o build_variants/libpem_$name.so
+echo build_variants/libpem_$name.so
