@@ -116,6 +116,7 @@ def main():
     ap.add_argument('--no-profile', action='store_true', help='reduced-QoI mode: never write j_ion (144 B/eval)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--seed', type=int, default=2)
+    ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL; default) or gloo (rehearsal on one GPU)')
     args = ap.parse_args()
 
     import torch
@@ -128,10 +129,14 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
-    torch.cuda.set_device(local_rank)
+    local_dev = local_rank % max(1, torch.cuda.device_count())   # == local_rank on a real multi-GPU node
+    torch.cuda.set_device(local_dev)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if args.dist_backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_dev))
+        else:
+            dist.init_process_group(args.dist_backend)
 
     lib = _lib.load()
     _lib.require_device()
@@ -141,9 +146,9 @@ def main():
     synth_inputs(batch, args.seed, rank)
     gathered = None
     if world > 1 and args.gather == 'qoi':
-        gathered = torch.empty((world,) + tuple(batch.qoi.shape), dtype=torch.float64, device=batch.device)
+        gathered = torch.empty((world * batch.qoi.shape[0], n), dtype=torch.float64, device=batch.device)
     elif world > 1 and args.gather == 'full':
-        gathered = torch.empty((world,) + tuple(batch.j_ion.shape), dtype=torch.float64, device=batch.device)
+        gathered = torch.empty((world * n, batch.j_ion.shape[1]), dtype=torch.float64, device=batch.device)
 
     def step():
         batch.run()

@@ -1,0 +1,78 @@
+"""The N > 1 path on CPU: world_size-2 (and 3, ragged shards) process groups over gloo.
+
+The evaluator injected here is the CPU oracle (tests may use it; the product's distributed module takes the
+evaluator as an argument and knows nothing about it).  Checked: shards tile the batch, the single all-gather
+restores global order, and the gathered QoIs equal a one-process evaluation bit for bit (samples are independent)."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / 'tests'))
+
+from hallthrusterpem_amd.distributed import all_gather_rows, evaluate_sharded, max_shard, shard_bounds  # noqa: E402
+
+
+def test_shard_bounds_tile_the_batch():
+    for n in (0, 1, 7, 64, 1000, 1_250_000 * 8 + 3):
+        for world in (1, 2, 3, 8):
+            edges = [shard_bounds(n, world, r) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
+            sizes = [hi - lo for lo, hi in edges]
+            assert max(sizes) - min(sizes) <= 1 and max(sizes) == max_shard(n, world)
+    with pytest.raises(ValueError):
+        shard_bounds(10, 2, 2)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_total, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from _inputs import coupled_inputs
+        from oracle import oracle_ctypes as oc
+        oc.set_threads(1)
+        x_all = coupled_inputs(n_total, seed=77)          # stands in for a counter-based sampler keyed by global index
+
+        def make_inputs(lo, hi):
+            return {k: v[lo:hi] for k, v in x_all.items()}
+
+        def evaluate(x):
+            return {k: torch.from_numpy(np.asarray(v)) for k, v in oc.coupled(x, 133.322).items()}
+
+        gathered, local = evaluate_sharded(n_total, make_inputs, evaluate)
+        lo, hi = shard_bounds(n_total, world, rank)
+        assert local['V_cc'].numel() == hi - lo
+        # a second collective with a different row count, straight through all_gather_rows
+        rows = torch.arange(lo, hi, dtype=torch.float64).repeat(2, 1)
+        idx = all_gather_rows(rows, n_total)
+        assert torch.equal(idx[0], torch.arange(n_total, dtype=torch.float64))
+        np.savez(Path(out_dir) / f'rank{rank}.npz', **{k: v.numpy() for k, v in gathered.items()})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,n_total', [(2, 1000), (3, 1001)])
+def test_sharded_forward_uq_matches_single_process(tmp_path, world, n_total):
+    from _inputs import coupled_inputs
+    from oracle import oracle_ctypes as oc
+    mp.spawn(_worker, args=(world, _free_port(), n_total, str(tmp_path)), nprocs=world, join=True)
+    want = oc.coupled(coupled_inputs(n_total, seed=77), 133.322)
+    for r in range(world):
+        got = np.load(tmp_path / f'rank{r}.npz')
+        for k in ('V_cc', 'div_angle', 'T_c'):
+            assert np.array_equal(got[k], want[k], equal_nan=True), (r, k)

@@ -36,7 +36,13 @@ for k, v in sorted(durs.items(), key=lambda kv: -sum(kv[1])):
         kern_mean_us = sum(v) / len(v) / 1e3
 lines.append('')
 for f in find('*kernel_stats.csv'):
-    lines += ['### rocprofv3 kernel_stats.csv', '', '```', f.read_text().strip(), '```', '']
+    lines += ['### rocprofv3 kernel_stats.csv (top rows, kernel names truncated)', '', '```']
+    with open(f) as fd:
+        for i, row in enumerate(csv.reader(fd)):
+            if i > 6:
+                break
+            lines.append(','.join(c[:90] for c in row))
+    lines += ['```', '']
 
 # ---- counters ---------------------------------------------------------------------------------------
 counters = defaultdict(list)
