@@ -6,9 +6,9 @@ from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
-SRC = PKG / 'csrc' / 'pem_kernels.hip'
+SRCS = [PKG / 'csrc' / 'pem_kernels.hip', PKG / 'csrc' / 'pem_sampler.hip']
 LIB = PKG / 'libpem_hip.so'
-DEPS = [SRC, PKG / 'csrc' / 'pem_tables.h', ROOT / 'include' / 'pem_hip.h']
+DEPS = SRCS + [PKG / 'csrc' / 'pem_tables.h', PKG / 'csrc' / 'pem_common.h', ROOT / 'include' / 'pem_hip.h']
 
 
 def hipcc() -> str:
@@ -30,7 +30,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     if not force and not needs_build():
         return LIB
     cmd = [hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
-           f'-I{ROOT / "include"}', f'-I{PKG / "csrc"}', str(SRC), '-o', str(LIB)]
+           f'-I{ROOT / "include"}', f'-I{PKG / "csrc"}', *[str(s) for s in SRCS], '-o', str(LIB)]
     if verbose:
         print(' '.join(cmd))
     env = dict(os.environ)

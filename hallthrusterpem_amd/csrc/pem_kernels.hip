@@ -34,6 +34,7 @@
 #include <cstring>
 #include <mutex>
 
+#include "pem_common.h"
 #include "pem_hip.h"
 
 #define PEM_TABLE_DECL static __device__ const
@@ -564,37 +565,11 @@ __global__ __launch_bounds__(BLOCK) void thruster_kernel(long long n, const doub
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-thread_local char g_err[512] = "";
 int g_lanes = 4;
 double g_angle_grid[NANG];
 std::once_flag g_grid_once;
-
-int fail(int code, const char* fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
-    va_end(ap);
-    return code;
-}
-
-#define HIP_TRY(expr)                                                                          \
-    do {                                                                                       \
-        hipError_t e_ = (expr);                                                                \
-        if (e_ != hipSuccess)                                                                  \
-            return fail(e_ == hipErrorNoDevice ? PEM_ERR_NO_DEVICE : PEM_ERR_HIP, "%s: %s", #expr, \
-                        hipGetErrorString(e_));                                                \
-    } while (0)
-
-int check_device() {
-    int cnt = 0;
-    hipError_t e = hipGetDeviceCount(&cnt);
-    if (e != hipSuccess || cnt == 0) {
-        (void)hipGetLastError();
-        return fail(PEM_ERR_NO_DEVICE, "no HIP device available (%s); libpem_hip has no CPU fallback",
-                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
-    }
-    return PEM_OK;
-}
+using pem::check_device;
+using pem::fail;
 
 // persistent grid of the fast kernel: as many single-wave workgroups as the LDS admits on every CU
 int fast_grid(size_t lds_bytes, long long ntiles, unsigned* grid) {
@@ -681,6 +656,13 @@ size_t padded(size_t bytes) { return (bytes + 255) & ~size_t(255); }
 
 }  // namespace
 
+namespace pem {
+char* error_buffer() {
+    thread_local char buf[512] = "";
+    return buf;
+}
+}  // namespace pem
+
 // =============================================================================================
 // C ABI
 // =============================================================================================
@@ -688,7 +670,7 @@ extern "C" {
 
 const char* pem_version(void) { return "hallthrusterpem_amd libpem_hip 0.1.0 (gfx950)"; }
 
-const char* pem_last_error(void) { return g_err; }
+const char* pem_last_error(void) { return pem::error_buffer(); }
 
 int pem_device_count(void) {
     int cnt = 0;

@@ -112,6 +112,30 @@ int pem_coupled_f64(size_t n, double torr2pa, double radius, const double* P_b, 
                     const double* sigma_cex, double* V_cc, double* I_B0, double* T, double* j_ion,
                     double* div_angle, double* T_c, uint8_t* invalid);
 
+/* ---- input samplers ------------------------------------------------------------------------------
+ * Stand in for `system.sample_inputs(N, ...)` (scripts/gen_data.py:238; scripts/pem_v0/sobol.py:46-66,
+ * monte_carlo.py:63-300).  amisc/uqtils are third-party and absent from the reference tree: parity is
+ * UNPINNED, the formulas are this library's own (see csrc/pem_sampler.hip).
+ * Counter-based (Philox4x32-10): out[d][i] depends only on (seed, stream_id, first_index + i, d), so
+ * any sharding / batching of a design yields the same design.  out is SoA: row d at out + d*ld, ld >= n.
+ * kind/a/b are HOST arrays of length ndim (<= PEM_SAMPLE_MAX_DIM):
+ *   PEM_DIST_UNIFORM     a + (b-a) u            PEM_DIST_LOGUNIFORM  10^(a + (b-a) u)  (a, b = log10 bounds)
+ *   PEM_DIST_NORMAL      a + b Phi^-1(u)  (mean a, standard deviation b)
+ * swap_dim builds Saltelli blocks: -1 plain (matrix A), -2 every dimension from stream_id+1 (matrix B),
+ * d >= 0 matrix A with column d taken from B.
+ * pem_sample_lhs_f64_dev: Latin hypercube over n_total strata per dimension (keyed Feistel permutation
+ * of the stratum index + jitter); samples first_index .. first_index+n-1 of that design.             */
+#define PEM_SAMPLE_MAX_DIM 32
+#define PEM_DIST_UNIFORM 0
+#define PEM_DIST_LOGUNIFORM 1
+#define PEM_DIST_NORMAL 2
+int pem_sample_f64_dev(size_t n, uint64_t first_index, uint64_t seed, uint32_t stream_id, int ndim,
+                       const int32_t* kind, const double* a, const double* b, int swap_dim, double* out,
+                       size_t ld, pem_stream_t stream);
+int pem_sample_lhs_f64_dev(size_t n, uint64_t first_index, uint64_t n_total, uint64_t seed, uint32_t stream_id,
+                           int ndim, const int32_t* kind, const double* a, const double* b, double* out,
+                           size_t ld, pem_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

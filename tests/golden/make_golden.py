@@ -217,6 +217,35 @@ def main():
         {'anom_max': 50.0, 'anom_min': 0.005}, thruster.PEM_TO_JULIA, thruster=None,
         config={'anom_model': {'type': 'GaussianBohm', 'hall_min': 0.00625, 'hall_max': 0.0625}},
         model_fidelity=None)
+    # ---- scripts/gen_data.py:104-174 `_filter_outputs` (NaN + IQR masks).  The script imports amisc at module
+    # level (absent), so only the two function definitions are pulled out of its AST and executed, with the
+    # one amisc name they read (COORDS_STR_ID, the '_coords' suffix of plume.py:157) supplied here.
+    import ast
+    src = (REF.parents[1] / 'scripts' / 'gen_data.py').read_text()
+    tree = ast.parse(src)
+    wanted = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ('_object_to_numeric', '_filter_outputs')]
+    ns = {'np': np, 'COORDS_STR_ID': '_coords'}
+    exec(compile(ast.Module(body=wanted, type_ignores=[]), 'gen_data.py[extract]', 'exec'), ns)
+    rng = np.random.default_rng(20260106)
+    N = 400
+    fo = {'V_cc': rng.normal(30, 2, N), 'T': rng.normal(0.08, 0.005, N), 'div_angle': rng.uniform(0.2, 0.6, N),
+          'j_ion': np.abs(rng.normal(0, 1, (N, 91))) + np.linspace(5, 0.1, 91), 'u_ion': rng.normal(10, 1, (N, 7, 3))}
+    fo['V_cc'][[3, 77]] = [55.0, -10.0]                  # scalar outliers
+    fo['T'][5] = np.nan                                  # NaN sample
+    fo['j_ion'][10] += 50.0                              # whole profile off -> field outlier
+    fo['j_ion'][11, :60] += 50.0                         # 60/91 = 66 % of entries off -> NOT an outlier (threshold 75 %)
+    fo['j_ion'][12, :70] += 50.0                         # 70/91 = 77 % -> outlier
+    fo['j_ion'][13, 4] = np.nan
+    fo['u_ion'][20] -= 30.0
+    fo['j_ion_coords'] = np.tile(np.linspace(0, 1, 91), (N, 1))   # must be skipped
+    fo['errors'] = np.zeros(N)                                   # must be skipped
+    with np.errstate(all='ignore'):
+        nan_q15, out_q15 = ns['_filter_outputs'](dict(fo), iqr_factor=1.5)
+        nan_q3, out_q3 = ns['_filter_outputs'](dict(fo), iqr_factor=3.0)
+    _save('filter_outputs', **{f'in_{k}': v for k, v in fo.items()},
+          **{f'nan15_{k}': v for k, v in nan_q15.items()}, **{f'out15_{k}': v for k, v in out_q15.items()},
+          **{f'nan30_{k}': v for k, v in nan_q3.items()}, **{f'out30_{k}': v for k, v in out_q3.items()})
+
     with open(OUT / 'thruster_host.json', 'w') as fd:
         json.dump({'fidelity': fid, 'convert_map': p2j, 'convert_to_julia': jd, 'convert_to_pem': back,
                    'format_twozone': fmt, 'format_gaussian': fmt_g,

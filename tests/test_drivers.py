@@ -1,0 +1,112 @@
+"""Sampling-loop drivers.
+
+`filter_outputs` is pinned: tests/golden/filter_outputs.npz holds what the reference's own `_filter_outputs`
+(scripts/gen_data.py:125-174) returned for the stored inputs.  The samplers and the Sobol' estimator are third-party
+in the reference (parity unpinned): on the GPU they are checked against the CPU oracle evaluated on the very same
+device-generated design, with the estimator restated in numpy."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import div_err, load_golden, rel_err
+from hallthrusterpem_amd import drivers
+
+
+def _golden_filter():
+    g = load_golden('filter_outputs')
+    ins = {k[3:]: g[k] for k in g if k.startswith('in_')}
+    return g, ins
+
+
+@pytest.mark.parametrize('as_torch', [False, True])
+def test_filter_outputs_matches_reference(as_torch):
+    g, ins = _golden_filter()
+    data = {k: (torch.from_numpy(v) if as_torch else v) for k, v in ins.items()}
+    for q, tag in ((1.5, '15'), (3.0, '30')):
+        nan_idx, out_idx = drivers.filter_outputs(data, iqr_factor=q)
+        assert sorted(nan_idx) == sorted(k[6:] for k in g if k.startswith(f'nan{tag}_'))     # coords / errors skipped
+        for k in nan_idx:
+            assert np.array_equal(np.asarray(nan_idx[k]), g[f'nan{tag}_{k}']), k
+            assert np.array_equal(np.asarray(out_idx[k]), g[f'out{tag}_{k}']), k
+    nan_idx, out_idx = drivers.filter_outputs(data, iqr_factor=1.5)
+    drop = np.asarray(drivers.discard_mask(nan_idx, out_idx))
+    assert drop.sum() == 2 and drop[5] and drop[13]                   # only the NaN samples
+    drop_all = np.asarray(drivers.discard_mask(nan_idx, out_idx, discard_outliers=True))
+    assert drop_all[[3, 77, 10, 12, 20]].all() and not drop_all[11]
+
+
+@pytest.mark.gpu
+def test_forward_uq_matches_oracle_on_device_design():
+    from hallthrusterpem_amd import constants
+    from hallthrusterpem_amd.models.coupled import COUPLED_INPUTS
+    from oracle import oracle_ctypes as oc
+    n = 50_003
+    res = drivers.forward_uq(n, seed=11, batch_size=16_384, keep_profile=True)      # several batches + ragged tail
+    x = {k: res['x'][i].cpu().numpy() for i, k in enumerate(COUPLED_INPUTS)}
+    want = oc.coupled(x, constants.TORR_2_PA)
+    assert rel_err(res['V_cc'].cpu().numpy(), want['V_cc']) <= 1e-10
+    assert rel_err(res['j_ion'].cpu().numpy(), want['j_ion']) <= 1e-10
+    assert div_err(res['div_angle'].cpu().numpy(), want['div_angle']) <= 1e-10
+    assert rel_err(res['T_c'].cpu().numpy(), want['T_c']) <= 1e-10
+    assert np.array_equal(res['invalid'].cpu().numpy(), want['invalid'])
+    # the design does not depend on batching or sharding
+    whole = drivers.forward_uq(n, seed=11, batch_size=1 << 20)
+    assert torch.equal(whole['x'], res['x']) and torch.equal(whole['T_c'], res['T_c'])
+    parts = [drivers.forward_uq(n, seed=11, rank=r, world=3) for r in range(3)]
+    assert torch.equal(torch.cat([p['V_cc'] for p in parts]), whole['V_cc'])
+    lhs = drivers.forward_uq(4096, seed=3, method='lhs')
+    va = ((lhs['x'][1] - 200) / 200 * 4096).floor().long().sort().values
+    assert torch.equal(va, torch.arange(4096, device=va.device))
+
+
+@pytest.mark.gpu
+def test_generate_data_layout_and_masks():
+    d = drivers.generate_data(20_000, seed=5, description='compression')
+    samples, outputs = d['compression']
+    assert set(samples) >= {'P_b', 'c0', 'sigma_cex'} and outputs['j_ion'].shape == (20_000, 91)
+    assert d['iqr_factor'] == 1.5 and set(d['nan_idx']) == set(outputs) == set(d['outlier_idx'])
+    assert not any(bool(v.any()) for v in d['nan_idx'].values())             # the priors never produce NaN
+    host = {k: v.cpu().numpy() for k, v in outputs.items()}
+    host['j_ion'] = np.log10(host['j_ion'])
+    nan_h, out_h = drivers.filter_outputs(host)
+    for k in out_h:                                                          # device masks == numpy masks
+        assert np.array_equal(d['outlier_idx'][k].cpu().numpy(), out_h[k]), k
+
+
+@pytest.mark.gpu
+def test_sobol_indices_against_numpy_estimator():
+    from hallthrusterpem_amd import constants, sampling
+    from hallthrusterpem_amd.models.coupled import COUPLED_INPUTS
+    from oracle import oracle_ctypes as oc
+    from oracle import sampler_np as snp
+    N = 20_000
+    fixed = {'P_b': 1e-5, 'V_a': 300.0, 'mdot_a': 5e-6}                      # operating point held, as sobol.py:104
+    got = drivers.sobol_indices(N, seed=9, fixed=fixed, batch_size=8192)
+    assert got['inputs'] == [k for k in COUPLED_INPUTS if k not in fixed] and got['evaluations'] == N * 14
+    # restate on the host: same design (numpy Philox), oracle as the model, same estimators
+    pri = dict(sampling.PEM_V0_PRIORS)
+    for k, v in fixed.items():
+        pri[k] = sampling.Prior(sampling.UNIFORM, v, v, 'fixed')
+    kind = [pri[k].kind for k in COUPLED_INPUTS]
+    a, b = [pri[k].a for k in COUPLED_INPUTS], [pri[k].b for k in COUPLED_INPUTS]
+
+    def f(swap):
+        x = snp.sample(N, 0, 9, 0, kind, a, b, swap_dim=swap)
+        o = oc.coupled({k: x[i] for i, k in enumerate(COUPLED_INPUTS)}, constants.TORR_2_PA)
+        return np.stack([o['V_cc'], o['div_angle'], o['T_c']], axis=1)
+    fA, fB = f(-1), f(-2)
+    pooled = np.concatenate([fA, fB])
+    var = pooled.var(axis=0)
+    for j, name in enumerate(got['inputs']):
+        fAB = f(COUPLED_INPUTS.index(name))
+        s1 = (fB * (fAB - fA)).mean(0) / var
+        st = ((fA - fAB) ** 2).mean(0) / (2 * var)
+        for i, q in enumerate(('V_cc', 'div_angle', 'T_c')):
+            assert float(got['S1'][q][j]) == pytest.approx(s1[i], abs=2e-9)
+            assert float(got['ST'][q][j]) == pytest.approx(st[i], abs=2e-9)
+    # structure of the model: V_cc only sees the cathode inputs; the divergence angle only the plume inputs
+    idx = {k: j for j, k in enumerate(got['inputs'])}
+    assert float(got['ST']['V_cc'][idx['c2']]) == 0.0 and float(got['ST']['V_cc'][idx['a_1']]) == 0.0
+    assert float(got['ST']['div_angle'][idx['T_e']]) == 0.0
+    assert float(got['S1']['V_cc'][idx['V_vac']]) > 0.5
+    assert 0.9 < float(sum(got['S1']['V_cc'])) < 1.1
