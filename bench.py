@@ -114,6 +114,7 @@ def main():
     ap.add_argument('--gather', choices=['qoi', 'full', 'none'], default='qoi',
                     help='what the N>1 all-gather moves: reduced QoIs (24 B/sample), full profiles, or nothing')
     ap.add_argument('--no-profile', action='store_true', help='reduced-QoI mode: never write j_ion (144 B/eval)')
+    ap.add_argument('--mixed', action='store_true', help='fp64 arithmetic, fp32 storage of the profile (508 B/eval)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--seed', type=int, default=2)
     ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL; default) or gloo (rehearsal on one GPU)')
@@ -142,7 +143,7 @@ def main():
     _lib.require_device()
     lanes = lib.pem_set_lanes_per_sample(args.lanes)
     n = args.samples_per_gpu
-    batch = CoupledBatch(n, profile=not args.no_profile)
+    batch = CoupledBatch(n, profile=not args.no_profile, mixed=args.mixed)
     synth_inputs(batch, args.seed, rank)
     gathered = None
     if world > 1 and args.gather == 'qoi':
@@ -188,11 +189,11 @@ def main():
     if rank == 0:
         bytes_per_launch = batch.bytes_per_eval * n
         achieved = bytes_per_launch / (kern_mean_ms * 1e-3) / 1e9
-        traffic = read_committed_traffic(n) if not args.no_profile else None
+        traffic = read_committed_traffic(n) if not (args.no_profile or args.mixed) else None
         line = {
             'metric': 'coupled PEM-v0 model evals/sec', 'value': world * n * args.steps / elapsed, 'unit': 'evals/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64' if not args.mixed else 'f64 (profile stored as f32)', 'data': 'synthetic',
             'config': {'workload': 'coupled cathode->thruster(analytic test double)->plume forward UQ, '
                                    'BASELINE configs[2] shard (1e7 samples / 8 GPUs), 91 angles, R=1 at 1.0 m',
                        'samples_per_gpu': n, 'global_samples_per_step': world * n, 'seed': args.seed,

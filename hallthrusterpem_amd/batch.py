@@ -14,25 +14,28 @@ QOI_NAMES = ('V_cc', 'div_angle', 'T_c')      # the reduced QoIs gathered across
 # algorithmic HBM bytes per evaluation, fp64
 BYTES_PER_EVAL_COUPLED = 15 * 8 + (1 + 91 + 1 + 1) * 8          # 872
 BYTES_PER_EVAL_REDUCED = 15 * 8 + 3 * 8                         # 144
+BYTES_PER_EVAL_MIXED = 15 * 8 + 3 * 8 + 91 * 4                  # 508 (fp32 profile)
 BYTES_PER_EVAL_PLUME = 9 * 8 + (91 + 1) * 8                     # 808 (824 with T -> T_c)
 BYTES_PER_EVAL_CATHODE = 7 * 8                                  # 56
 
 
 class CoupledBatch:
-    def __init__(self, n: int, device=None, profile: bool = True, sweep_radius: float = 1.0):
+    def __init__(self, n: int, device=None, profile: bool = True, sweep_radius: float = 1.0, mixed: bool = False):
         import torch
         _lib.load()
         _lib.require_device()
         self.n = int(n)
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         self.profile = bool(profile)
+        self.mixed = bool(mixed) and self.profile          # fp64 arithmetic, fp32 storage of the profile
         self.radius = float(sweep_radius)
         f64 = dict(dtype=torch.float64, device=self.device)
         self.inputs = torch.empty((len(COUPLED_INPUTS), self.n), **f64)         # SoA: one row per variable
         self.qoi = torch.empty((len(QOI_NAMES), self.n), **f64)                  # V_cc, div_angle, T_c
         self.I_B0 = torch.empty(self.n, **f64)
         self.T = torch.empty(self.n, **f64)
-        self.j_ion = torch.empty((self.n, _lib.NANGLE), **f64) if self.profile else None
+        self.j_ion = (torch.empty((self.n, _lib.NANGLE), dtype=torch.float32 if self.mixed else torch.float64,
+                                  device=self.device) if self.profile else None)
         self.invalid = torch.empty(self.n, dtype=torch.uint8, device=self.device)
         self._bind()
 
@@ -52,8 +55,8 @@ class CoupledBatch:
         """Enqueue one coupled evaluation of the whole batch (asynchronous)."""
         import torch
         s = torch.cuda.current_stream(self.device) if stream is None else stream
-        rc = _lib.load().pem_coupled_f64_dev(self.n, constants.TORR_2_PA, self.radius, *self._in_ptrs,
-                                             *self._out_ptrs, C.c_void_p(s.cuda_stream))
+        fn = _lib.load().pem_coupled_mixed_dev if self.mixed else _lib.load().pem_coupled_f64_dev
+        rc = fn(self.n, constants.TORR_2_PA, self.radius, *self._in_ptrs, *self._out_ptrs, C.c_void_p(s.cuda_stream))
         _lib.check(rc)
 
     def outputs(self) -> dict:
@@ -65,4 +68,6 @@ class CoupledBatch:
 
     @property
     def bytes_per_eval(self) -> int:
-        return BYTES_PER_EVAL_COUPLED if self.profile else BYTES_PER_EVAL_REDUCED
+        if not self.profile:
+            return BYTES_PER_EVAL_REDUCED
+        return BYTES_PER_EVAL_MIXED if self.mixed else BYTES_PER_EVAL_COUPLED

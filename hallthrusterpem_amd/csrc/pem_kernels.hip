@@ -33,6 +33,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 
 #include "pem_common.h"
 #include "pem_hip.h"
@@ -148,6 +149,7 @@ struct PlumeIO {
     const double *P_b, *c0, *c1, *c2, *c3, *c4, *c5, *sigma, *I_B0, *T;
     double *j_ion, *div, *Tc;
     uint8_t* invalid;
+    float* j_ion_f32;  // mixed mode: the profile is computed in fp64 and stored as fp32
 };
 
 struct CoupledIO {
@@ -210,15 +212,17 @@ __device__ __forceinline__ SampleIn<COUPLED> load_sample(const PlumeIO& io, cons
 // fast path: R = 1.  One wave per workgroup, persistent over 64-sample tiles.
 //   L        lanes that share a sample during the rounds (2, 4 or 8)
 //   COUPLED  cathode + thruster stages are evaluated in front of the plume (inputs from CoupledIO)
-//   WRITE_J  stage and store the 91-point profile (false = reduced-QoI mode)
+//   JMODE    0: reduced-QoI mode, no profile;  1: stage and store the 91-point profile as fp64;
+//            2: mixed mode -- same fp64 arithmetic, profile rounded once to fp32 when it is staged
 // LDS map (doubles): simpson[96][2] | dpoly[32*12] | params[9][64] | partial[64*L][2] | tile[S*91] | 2 (sink)
 // The Simpson table is padded with zero weights to L*CH <= 96 entries so the angle loop needs no branch.
 // ---------------------------------------------------------------------------------------------
 constexpr int NPARAM = 9;   // X1 X2 jcex | r0 G E (beam 1) | r0 G E (beam 2)
 constexpr int NSIMP = 96;   // >= L*CH for L in {2, 4, 8}
-template <int L, bool WRITE_J>
+template <int L, int JMODE>
 constexpr int fast_lds_doubles() {
-    return 2 * NSIMP + PEM_NDI * PEM_NDC + NPARAM * WAVE + 2 * WAVE * L + (WRITE_J ? (WAVE / L) * NANG + 2 : 0);
+    return 2 * NSIMP + PEM_NDI * PEM_NDC + NPARAM * WAVE + 2 * WAVE * L +
+           (JMODE == 1 ? (WAVE / L) * NANG + 2 : JMODE == 2 ? ((WAVE / L) * NANG + 4) / 2 : 0);
 }
 
 // Order LDS traffic inside ONE wave (the workgroup is a single wave): the LDS unit executes a wave's
@@ -256,19 +260,23 @@ struct WaveLds {
 // One 64-sample tile.  FULL = every sample of the tile exists (the steady state of the persistent loop:
 // no bounds checks and a fixed number of stores, so the compiler can count them); FULL = false is the
 // ragged last tile of a batch.
-template <int L, bool COUPLED, bool WRITE_J, bool FULL>
+template <int L, bool COUPLED, int JMODE, bool FULL>
 __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO& cio, const WaveLds& m,
                                              const SampleIn<COUPLED>& in, long long t, int lane, double rad,
                                              double inv_r2, double inv_2pi_r2) {
     constexpr int S = WAVE / L;             // samples per round
     constexpr int CH = (NANG + L - 1) / L;  // angles per lane
-    constexpr int TILE = S * NANG;          // doubles per round tile
-    constexpr int PAIRS = TILE / 2;         // 16-byte pieces of a full round tile (TILE is even)
+    constexpr int TILE = S * NANG;          // profile values per round tile
+    constexpr bool WRITE_J = JMODE != 0;
+    using JT = typename std::conditional<JMODE == 2, float, double>::type;   // element type of the stored profile
+    constexpr int PER16 = 16 / (int)sizeof(JT);                              // values per 16-byte piece
+    constexpr int PAIRS = TILE / PER16;     // 16-byte pieces of a full round tile (TILE divides evenly)
+    static_assert(TILE % PER16 == 0, "a round tile is a whole number of 16-byte pieces");
     const int s = lane % S, c = lane / S;   // role during the rounds
     const int k0 = c * CH;
     const double2* my_w = m.simpson + k0;   // this lane's folded Simpson weights
     double* params = m.params;
-    double* tile = m.tile;
+    JT* tile = reinterpret_cast<JT*>(m.tile);
     const long long g = t * WAVE + lane;
     const bool live = FULL || g < io.n;
 
@@ -352,11 +360,11 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
             const double f = X1 + X2;     // j_beam + j_scat
             const double ji = f + jcex;   // plume.py:102
             if ((L - 1) * CH + j < NANG) {  // an angle every chunk has (compile-time after unrolling)
-                if constexpr (WRITE_J) tile[s * NANG + k0 + j] = ji;
+                if constexpr (WRITE_J) tile[s * NANG + k0 + j] = (JT)ji;
                 lo = fmin(lo, ji);
             } else {                        // past 90 degrees in the last chunk: store to the sink, skip the min
                 const bool in_range = k0 + j < NANG;
-                if constexpr (WRITE_J) tile[in_range ? s * NANG + k0 + j : TILE] = ji;
+                if constexpr (WRITE_J) tile[in_range ? s * NANG + k0 + j : TILE] = (JT)ji;
                 lo = fmin(lo, in_range ? ji : __builtin_inf());
             }
             den = fma(wq[j].x, f, den);
@@ -376,28 +384,31 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
         if constexpr (WRITE_J) {
             if ((bad >> s) & 1) {  // plume.py:106: the whole profile of an invalid sample becomes 1e-20 (rare)
                 for (int j = 0; j < CH; ++j)
-                    if (k0 + j < NANG) tile[s * NANG + k0 + j] = 1e-20;
+                    if (k0 + j < NANG) tile[s * NANG + k0 + j] = (JT)1e-20;
             }
             wave_lds_sync();
-            // the round's S*91 doubles are one contiguous, 16-byte aligned block of j_ion
+            // the round's S*91 values are one contiguous, 16-byte aligned block of j_ion
             const long long first = t * WAVE + (long long)round * S;
-            const double2* src2 = reinterpret_cast<const double2*>(tile);
+            JT* jbase;
+            if constexpr (JMODE == 2) jbase = io.j_ion_f32; else jbase = io.j_ion;
             if constexpr (FULL) {
-                f64x2* dst2 = reinterpret_cast<f64x2*>(io.j_ion + first * NANG);
+                f64x2* dst2 = reinterpret_cast<f64x2*>(jbase + first * NANG);
                 const f64x2* srcv = reinterpret_cast<const f64x2*>(tile);
 #pragma unroll
                 for (int it = 0; it < PAIRS / WAVE; ++it) stream_store(srcv[it * WAVE + lane], &dst2[it * WAVE + lane]);
                 if (PAIRS % WAVE != 0 && lane < PAIRS % WAVE)
                     stream_store(srcv[(PAIRS / WAVE) * WAVE + lane], &dst2[(PAIRS / WAVE) * WAVE + lane]);
             } else {
-                long long valid = (io.n - first) * NANG;   // doubles of this round that exist
+                long long valid = (io.n - first) * NANG;   // values of this round that exist
                 if (valid > TILE) valid = TILE;
                 if (valid > 0) {
-                    double* dst = io.j_ion + first * NANG;
-                    double2* dst2 = reinterpret_cast<double2*>(dst);
-                    const int pairs = (int)(valid >> 1);
-                    for (int i = lane; i < pairs; i += WAVE) dst2[i] = src2[i];
-                    if ((valid & 1) && lane == 0) dst[valid - 1] = tile[valid - 1];
+                    JT* dst = jbase + first * NANG;
+                    f64x2* dst2 = reinterpret_cast<f64x2*>(dst);
+                    const f64x2* srcv = reinterpret_cast<const f64x2*>(tile);
+                    const int pieces = (int)(valid / PER16);
+                    for (int i = lane; i < pieces; i += WAVE) dst2[i] = srcv[i];
+                    const int rest = (int)(valid - (long long)pieces * PER16);
+                    if (lane < rest) dst[pieces * PER16 + lane] = tile[pieces * PER16 + lane];
                 }
             }
             wave_lds_sync();
@@ -428,7 +439,7 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
     wave_lds_sync();  // params / partial are rewritten by the next tile
 }
 
-template <int L, bool COUPLED, bool WRITE_J>
+template <int L, bool COUPLED, int JMODE>
 __global__ __launch_bounds__(WAVE) void plume_r1_kernel(PlumeIO io, CoupledIO cio, long long ntiles) {
     static_assert(L == 2 || L == 4 || L == 8, "lanes per sample");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -460,14 +471,14 @@ __global__ __launch_bounds__(WAVE) void plume_r1_kernel(PlumeIO io, CoupledIO ci
         for (; t < nfull; t += gridDim.x) {
             const SampleIn<COUPLED> in = nxt;
             if (t + gridDim.x < nfull) nxt = load_sample<COUPLED>(io, cio, (t + gridDim.x) * WAVE + lane);
-            process_tile<L, COUPLED, WRITE_J, true>(io, cio, m, in, t, lane, rad, inv_r2, inv_2pi_r2);
+            process_tile<L, COUPLED, JMODE, true>(io, cio, m, in, t, lane, rad, inv_r2, inv_2pi_r2);
         }
     }
     // the ragged last tile (n % 64 samples) goes to the wave that would have been next in line for it
     if (nfull < ntiles && (nfull % gridDim.x) == blockIdx.x) {
         const long long g = nfull * WAVE + lane;
         const SampleIn<COUPLED> in = load_sample<COUPLED>(io, cio, g < io.n ? g : io.n - 1);
-        process_tile<L, COUPLED, WRITE_J, false>(io, cio, m, in, nfull, lane, rad, inv_r2, inv_2pi_r2);
+        process_tile<L, COUPLED, JMODE, false>(io, cio, m, in, nfull, lane, rad, inv_r2, inv_2pi_r2);
     }
 }
 
@@ -594,24 +605,24 @@ int fast_grid(size_t lds_bytes, long long ntiles, unsigned* grid) {
     return PEM_OK;
 }
 
-template <int L, bool COUPLED, bool WRITE_J>
+template <int L, bool COUPLED, int JMODE>
 int launch_r1(const PlumeIO& io, const CoupledIO& cio, hipStream_t st) {
-    const size_t lds = (size_t)fast_lds_doubles<L, WRITE_J>() * 8;
+    const size_t lds = (size_t)fast_lds_doubles<L, JMODE>() * 8;
     const long long ntiles = (io.n + WAVE - 1) / WAVE;
     unsigned grid = 0;
     if (int rc = fast_grid(lds, ntiles, &grid)) return rc;
-    auto kern = plume_r1_kernel<L, COUPLED, WRITE_J>;
+    auto kern = plume_r1_kernel<L, COUPLED, JMODE>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), lds, st, io, cio, ntiles);
     HIP_TRY(hipGetLastError());
     return PEM_OK;
 }
 
-template <bool COUPLED, bool WRITE_J>
+template <bool COUPLED, int JMODE>
 int dispatch_lanes(const PlumeIO& io, const CoupledIO& cio, hipStream_t st) {
     switch (g_lanes) {
-        case 2: return launch_r1<2, COUPLED, WRITE_J>(io, cio, st);
-        case 8: return launch_r1<8, COUPLED, WRITE_J>(io, cio, st);
-        default: return launch_r1<4, COUPLED, WRITE_J>(io, cio, st);
+        case 2: return launch_r1<2, COUPLED, JMODE>(io, cio, st);
+        case 8: return launch_r1<8, COUPLED, JMODE>(io, cio, st);
+        default: return launch_r1<4, COUPLED, JMODE>(io, cio, st);
     }
 }
 
@@ -751,7 +762,7 @@ int pem_plume_f64_dev(size_t n, int n_radii, const double* radii, double torr2pa
     if (int rc = check_device()) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     PlumeIO io{(long long)n, torr2pa, radii[0], P_b, c0, c1, c2, c3, c4, c5, sigma_cex, I_B0, T, j_ion, div_angle, T_c, invalid};
-    if (n_radii == 1 && aligned16(j_ion)) return dispatch_lanes<false, true>(io, CoupledIO{}, st);
+    if (n_radii == 1 && aligned16(j_ion)) return dispatch_lanes<false, 1>(io, CoupledIO{}, st);
 
     // general path: radii go to the device through a small stream-ordered allocation
     double* d_radii = nullptr;
@@ -782,7 +793,25 @@ int pem_coupled_f64_dev(size_t n, double torr2pa, double radius, const double* P
     hipStream_t st = static_cast<hipStream_t>(stream);
     PlumeIO io{(long long)n, torr2pa, radius, P_b, c0, c1, c2, c3, c4, c5, sigma_cex, nullptr, nullptr, j_ion, div_angle, T_c, invalid};
     CoupledIO cio{V_a, T_e, V_vac, Pstar, P_T, mdot_a, a_1, V_cc, I_B0, T};
-    return j_ion ? dispatch_lanes<true, true>(io, cio, st) : dispatch_lanes<true, false>(io, cio, st);
+    return j_ion ? dispatch_lanes<true, 1>(io, cio, st) : dispatch_lanes<true, 0>(io, cio, st);
+}
+
+// ---- coupled, mixed precision: fp64 arithmetic, the 91-point profile stored as fp32 -----------------
+int pem_coupled_mixed_dev(size_t n, double torr2pa, double radius, const double* P_b, const double* V_a, const double* T_e,
+                          const double* V_vac, const double* Pstar, const double* P_T, const double* mdot_a,
+                          const double* a_1, const double* c0, const double* c1, const double* c2, const double* c3,
+                          const double* c4, const double* c5, const double* sigma_cex, double* V_cc, double* I_B0,
+                          double* T, float* j_ion_f32, double* div_angle, double* T_c, uint8_t* invalid,
+                          pem_stream_t stream) {
+    if (n == 0) return PEM_OK;
+    if (!P_b || !V_a || !T_e || !V_vac || !Pstar || !P_T || !mdot_a || !a_1 || !c0 || !c1 || !c2 || !c3 || !c4 || !c5 ||
+        !sigma_cex || !V_cc || !div_angle || !T_c || !j_ion_f32)
+        return fail(PEM_ERR_INVALID_ARG, "pem_coupled_mixed: NULL array");
+    if (!aligned16(j_ion_f32)) return fail(PEM_ERR_INVALID_ARG, "pem_coupled_mixed: j_ion_f32 must be 16-byte aligned");
+    if (int rc = check_device()) return rc;
+    PlumeIO io{(long long)n, torr2pa, radius, P_b, c0, c1, c2, c3, c4, c5, sigma_cex, nullptr, nullptr, nullptr, div_angle, T_c, invalid, j_ion_f32};
+    CoupledIO cio{V_a, T_e, V_vac, Pstar, P_T, mdot_a, a_1, V_cc, I_B0, T};
+    return dispatch_lanes<true, 2>(io, cio, static_cast<hipStream_t>(stream));
 }
 
 // =============================================================================================

@@ -51,11 +51,13 @@ __device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {
     return (double)((((uint64_t)(hi >> 5)) << 26) | (uint64_t)(lo >> 6)) * 0x1.0p-53;
 }
 
+// products and sums rounded separately (no FMA) so that a host restatement reproduces the design bit for bit
 __device__ __forceinline__ double transform(int kind, double a, double b, double u) {
+#pragma clang fp contract(off)
     switch (kind) {
-        case PEM_DIST_LOGUNIFORM: return exp(2.302585092994045684 * fma(b - a, u, a));   // 10^(a + (b-a) u)
-        case PEM_DIST_NORMAL: return fma(b, normcdfinv(u), a);                          // mean a, std b
-        default: return fma(b - a, u, a);                                                // uniform on [a, b)
+        case PEM_DIST_LOGUNIFORM: return exp(2.302585092994045684 * (a + (b - a) * u));   // 10^(a + (b-a) u)
+        case PEM_DIST_NORMAL: return a + b * normcdfinv(u);                              // mean a, std b
+        default: return a + (b - a) * u;                                                  // uniform on [a, b)
     }
 }
 

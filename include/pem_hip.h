@@ -112,6 +112,16 @@ int pem_coupled_f64(size_t n, double torr2pa, double radius, const double* P_b, 
                     const double* sigma_cex, double* V_cc, double* I_B0, double* T, double* j_ion,
                     double* div_angle, double* T_c, uint8_t* invalid);
 
+/* Mixed precision (BASELINE.json configs[4], "fp64 -> fp32 mixed with tolerance check"): identical fp64
+ * arithmetic; only the 91-point profile is rounded once to fp32 when it is stored (j_ion_f32: [n][91]
+ * floats, 16-byte aligned).  508 instead of 872 algorithmic bytes per evaluation.  Device pointers only.  */
+int pem_coupled_mixed_dev(size_t n, double torr2pa, double radius, const double* P_b, const double* V_a,
+                          const double* T_e, const double* V_vac, const double* Pstar, const double* P_T,
+                          const double* mdot_a, const double* a_1, const double* c0, const double* c1,
+                          const double* c2, const double* c3, const double* c4, const double* c5,
+                          const double* sigma_cex, double* V_cc, double* I_B0, double* T, float* j_ion_f32,
+                          double* div_angle, double* T_c, uint8_t* invalid, pem_stream_t stream);
+
 /* ---- input samplers ------------------------------------------------------------------------------
  * Stand in for `system.sample_inputs(N, ...)` (scripts/gen_data.py:238; scripts/pem_v0/sobol.py:46-66,
  * monte_carlo.py:63-300).  amisc/uqtils are third-party and absent from the reference tree: parity is

@@ -240,3 +240,25 @@ def test_config2_full_size_properties(pem, oc):
     resolved = a1 > 0.1
     rel = ((cur - xd['I_B0']).abs() / xd['I_B0'])[resolved]
     assert float(rel.max()) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------- mixed precision
+def test_mixed_precision_profile_tolerance(pem, oc):
+    """BASELINE.json configs[4]: fp64 -> fp32 mixed run compared with fp64 on identical inputs.
+    The mixed mode keeps the fp64 arithmetic and rounds the profile once to fp32, so the scalars are bit-identical
+    and every profile entry is within half an fp32 ulp (6e-8 relative) of the fp64 result."""
+    import torch
+    from hallthrusterpem_amd.batch import CoupledBatch
+    n = 200_003
+    x = coupled_inputs(n, seed=21)
+    full, mixed = CoupledBatch(n), CoupledBatch(n, mixed=True)
+    full.set_inputs(x)
+    mixed.set_inputs(x)
+    full.run()
+    mixed.run()
+    torch.cuda.synchronize()
+    assert mixed.j_ion.dtype == torch.float32 and mixed.bytes_per_eval == 508
+    assert torch.equal(full.qoi, mixed.qoi) and torch.equal(full.invalid, mixed.invalid)
+    assert torch.equal(full.j_ion.float(), mixed.j_ion)                 # exactly the correctly rounded fp64 value
+    rel = ((mixed.j_ion.double() - full.j_ion) / full.j_ion).abs()
+    assert float(rel.max()) <= 2.0 ** -24 and float(rel.flatten().kthvalue(int(0.999 * rel.numel())).values) <= 2.0 ** -24
