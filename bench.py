@@ -145,35 +145,68 @@ def main():
     n = args.samples_per_gpu
     batch = CoupledBatch(n, profile=not args.no_profile, mixed=args.mixed)
     synth_inputs(batch, args.seed, rank)
-    gathered = None
-    if world > 1 and args.gather == 'qoi':
-        gathered = torch.empty((world * batch.qoi.shape[0], n), dtype=torch.float64, device=batch.device)
-    elif world > 1 and args.gather == 'full':
-        gathered = torch.empty((world * n, batch.j_ion.shape[1]), dtype=torch.float64, device=batch.device)
+    # N > 1: the all-gather of step i runs beside the evaluation of step i+1 (RCCL works on its own stream):
+    # two batches alternate so a QoI buffer is not rewritten while it is still being sent.
+    nbuf = 2 if (world > 1 and args.gather != 'none') else 1
+    batches = [batch]
+    for _ in range(nbuf - 1):
+        b2 = CoupledBatch(n, profile=not args.no_profile, mixed=args.mixed)
+        b2.inputs.copy_(batch.inputs)
+        batches.append(b2)
+    gathered, pending = [], [None] * nbuf
+    for b in batches:
+        if world > 1 and args.gather == 'qoi':
+            gathered.append(torch.empty((world * b.qoi.shape[0], n), dtype=torch.float64, device=b.device))
+        elif world > 1 and args.gather == 'full':
+            gathered.append(torch.empty((world * n, b.j_ion.shape[1]), dtype=b.j_ion.dtype, device=b.device))
+    counter = [0]
 
     def step():
-        batch.run()
-        if gathered is not None:
-            dist.all_gather_into_tensor(gathered, batch.qoi if args.gather == 'qoi' else batch.j_ion)
+        i = counter[0] % nbuf
+        counter[0] += 1
+        if pending[i] is not None:
+            pending[i].wait()               # stream-level: this buffer's previous gather must have read it
+            pending[i] = None
+        batches[i].run()
+        if gathered:
+            src = batches[i].qoi if args.gather == 'qoi' else batches[i].j_ion
+            pending[i] = dist.all_gather_into_tensor(gathered[i], src, async_op=True)
+
+    def drain():
+        for i, w in enumerate(pending):
+            if w is not None:
+                w.wait()
+                pending[i] = None
 
     def fence():
+        drain()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(nsteps):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=batch.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
     for _ in range(args.warmup):
         step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=batch.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed(args.steps)
+    # N > 1: also the gather-free rate of the same shards (reported beside `value`, SURVEY.md section 8e "report both")
+    elapsed_nogather = None
+    if gathered:
+        saved, gathered = gathered, []
+        elapsed_nogather = timed(args.steps)
+        gathered = saved
 
     # kernel-only duration: HIP events on the launch stream around each launch (outside the timed region)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(args.steps, 50))]
@@ -198,7 +231,9 @@ def main():
                                    'BASELINE configs[2] shard (1e7 samples / 8 GPUs), 91 angles, R=1 at 1.0 m',
                        'samples_per_gpu': n, 'global_samples_per_step': world * n, 'seed': args.seed,
                        'TORR_2_PA': 133.322, 'lanes_per_sample': lanes, 'profile_written': not args.no_profile,
-                       'gather': args.gather if world > 1 else 'none', 'parallelism': f'sample-shard x{world}',
+                       'gather': (args.gather + ', overlapped with the next step') if (world > 1 and args.gather != 'none') else 'none',
+                       'value_without_gather': (world * n * args.steps / elapsed_nogather) if elapsed_nogather else None,
+                       'parallelism': f'sample-shard x{world}',
                        'invalid_fraction': frac_invalid},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
