@@ -35,6 +35,8 @@ SIGNATURES = {
     'pem_plume_f64': (C.c_int, [_sz, C.c_int, _dp, _f8] + [_dp] * 10 + [_dp] * 4),
     'pem_thruster_f64_dev': (C.c_int, [_sz] + [_dp] * 4 + [_dp] * 8 + [_dp]),
     'pem_thruster_f64': (C.c_int, [_sz] + [_dp] * 4 + [_dp] * 8),
+    'pem_thruster_uion_f64_dev': (C.c_int, [_sz, _dp, _f8, _f8, C.c_int, _dp, _dp, _dp]),
+    'pem_thruster_filter_f64_dev': (C.c_int, [_sz, C.c_int, _dp, _dp, _f8, C.c_int, _dp, _dp, _dp, _dp]),
     'pem_coupled_f64_dev': (C.c_int, [_sz, _f8, _f8] + [_dp] * 15 + [_dp] * 7 + [_dp]),
     'pem_coupled_f64': (C.c_int, [_sz, _f8, _f8] + [_dp] * 15 + [_dp] * 7),
     'pem_coupled_mixed_dev': (C.c_int, [_sz, _f8, _f8] + [_dp] * 15 + [_dp] * 7 + [_dp]),

@@ -573,6 +573,78 @@ __global__ __launch_bounds__(BLOCK) void thruster_kernel(long long n, const doub
     }
 }
 
+// u_ion(z) of sim_hallthruster.jl:46-47 on z = range(z0, z1, length = ncells): one row per sample, lanes along z
+__global__ __launch_bounds__(BLOCK) void thruster_uion_kernel(long long n, const double* __restrict__ v_exh, double z0,
+                                                              double z1, int ncells, double* __restrict__ z_out,
+                                                              double* __restrict__ u_ion) {
+    const long long total = n * ncells;
+    const long long stride = (long long)gridDim.x * BLOCK;
+    for (long long idx = (long long)blockIdx.x * BLOCK + threadIdx.x; idx < total; idx += stride) {
+        const long long i = idx / ncells;
+        const int c = (int)(idx - i * ncells);
+        const double z = z0 + (z1 - z0) * ((double)c / (double)(ncells - 1));
+        if (i == 0 && z_out) z_out[c] = z;
+        u_ion[idx] = v_exh[i] / (1.0 + exp(-100.0 * (z - 0.04)));
+    }
+}
+
+// The two filters hallthruster_jl applies to a finished run, batched (thruster.py:490-502):
+//   bit 0: thrust < 0 or beam current < 0 (non-physical);  bit 1: the ion velocity peaks before `threshold`
+// One wave per sample row: strided argmax (first maximum wins, as np.argmax) + wave reduction.
+__global__ __launch_bounds__(BLOCK) void thruster_filter_kernel(long long n, int ncells, const double* __restrict__ u_ion,
+                                                                const double* __restrict__ z, double threshold,
+                                                                int use_shock, const double* __restrict__ T,
+                                                                const double* __restrict__ I_B0,
+                                                                uint8_t* __restrict__ flags) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = ((long long)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * BLOCK) >> 6;
+    for (long long i = wave; i < n; i += nwaves) {
+        int flag = 0;
+        if (lane == 0) {
+            const double t = T ? T[i] : 0.0, b = I_B0 ? I_B0[i] : 0.0;
+            flag = (t < 0.0 || b < 0.0) ? 1 : 0;
+        }
+        if (use_shock) {
+            double best = -__builtin_inf();
+            int where = 0x7fffffff;
+            bool any_nan = false;
+            for (int c = lane; c < ncells; c += 64) {
+                const double u = u_ion[i * ncells + c];
+                any_nan |= (u != u);
+                if (u > best) {
+                    best = u;
+                    where = c;
+                }
+            }
+            // np.argmax returns the first NaN if there is one; otherwise the first maximum
+            int nan_at = 0x7fffffff;
+            if (any_nan)
+                for (int c = lane; c < ncells; c += 64)
+                    if (u_ion[i * ncells + c] != u_ion[i * ncells + c]) {
+                        nan_at = c;
+                        break;
+                    }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                const double ob = __shfl_xor(best, m);
+                const int ow = __shfl_xor(where, m);
+                const int on = __shfl_xor(nan_at, m);
+                if (ob > best || (ob == best && ow < where)) {
+                    best = ob;
+                    where = ow;
+                }
+                nan_at = on < nan_at ? on : nan_at;
+            }
+            if (lane == 0) {
+                const int arg = nan_at != 0x7fffffff ? nan_at : (where == 0x7fffffff ? 0 : where);
+                if (z[arg] < threshold) flag |= 2;
+            }
+        }
+        if (lane == 0) flags[i] = (uint8_t)flag;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -812,6 +884,35 @@ int pem_coupled_mixed_dev(size_t n, double torr2pa, double radius, const double*
     PlumeIO io{(long long)n, torr2pa, radius, P_b, c0, c1, c2, c3, c4, c5, sigma_cex, nullptr, nullptr, nullptr, div_angle, T_c, invalid, j_ion_f32};
     CoupledIO cio{V_a, T_e, V_vac, Pstar, P_T, mdot_a, a_1, V_cc, I_B0, T};
     return dispatch_lanes<true, 2>(io, cio, static_cast<hipStream_t>(stream));
+}
+
+// ---- thruster profile + filters ----------------------------------------------------------------------
+int pem_thruster_uion_f64_dev(size_t n, const double* v_exh, double z0, double z1, int ncells, double* z, double* u_ion,
+                              pem_stream_t stream) {
+    if (ncells < 2) return fail(PEM_ERR_INVALID_ARG, "pem_thruster_uion: need at least 2 grid points");
+    if (n == 0) return PEM_OK;
+    if (!v_exh || !u_ion) return fail(PEM_ERR_INVALID_ARG, "pem_thruster_uion: NULL array");
+    if (int rc = check_device()) return rc;
+    size_t blocks = (n * (size_t)ncells + BLOCK - 1) / BLOCK;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(thruster_uion_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, static_cast<hipStream_t>(stream),
+                       (long long)n, v_exh, z0, z1, ncells, z, u_ion);
+    HIP_TRY(hipGetLastError());
+    return PEM_OK;
+}
+
+int pem_thruster_filter_f64_dev(size_t n, int ncells, const double* u_ion, const double* z, double shock_threshold,
+                                int use_shock, const double* T, const double* I_B0, uint8_t* flags, pem_stream_t stream) {
+    if (n == 0) return PEM_OK;
+    if (!flags) return fail(PEM_ERR_INVALID_ARG, "pem_thruster_filter: NULL flags");
+    if (use_shock && (!u_ion || !z || ncells < 1)) return fail(PEM_ERR_INVALID_ARG, "pem_thruster_filter: shock filter needs u_ion and z");
+    if (int rc = check_device()) return rc;
+    size_t blocks = (n * 64 + BLOCK - 1) / BLOCK;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(thruster_filter_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, static_cast<hipStream_t>(stream),
+                       (long long)n, ncells, u_ion, z, shock_threshold, use_shock, T, I_B0, flags);
+    HIP_TRY(hipGetLastError());
+    return PEM_OK;
 }
 
 // =============================================================================================

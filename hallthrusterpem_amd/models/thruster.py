@@ -148,11 +148,14 @@ def _format_hallthruster_jl_input(thruster_inputs: dict, pem_to_julia: dict, thr
     return doc
 
 
-def check_thruster_outputs(outputs: dict, shock_threshold: float | None = None) -> np.ndarray:
+def check_thruster_outputs(outputs: dict, shock_threshold: float | None = None):
     """The two filters `hallthruster_jl` applies to a finished run (thruster.py:490-502), batched.
 
     Scalar QoIs raise ValueError exactly as the reference does; array QoIs return a boolean `bad` mask
-    (True = the reference would have raised for that sample) so a sampling loop can drop them."""
+    (True = the reference would have raised for that sample) so a sampling loop can drop them.  CUDA tensors are
+    filtered on the device (`pem_thruster_filter_f64_dev`) and a CUDA bool tensor comes back."""
+    if m.any_device_tensor([v for v in outputs.values() if v is not None]):
+        return _check_on_device(outputs, shock_threshold)
     thrust = np.asarray(outputs.get('T', 0), dtype=np.float64)
     beam = np.asarray(outputs.get('I_B0', 0), dtype=np.float64)
     bad = (thrust < 0) | (beam < 0)
@@ -171,30 +174,70 @@ def check_thruster_outputs(outputs: dict, shock_threshold: float | None = None) 
     return bad
 
 
+def _check_on_device(outputs: dict, shock_threshold):
+    import ctypes as C
+
+    import torch
+    lib = _lib.load()
+    dev = m.pick_device([v for v in outputs.values() if v is not None])
+    u, z = outputs.get('u_ion'), outputs.get('u_ion_coords')
+    use_shock = shock_threshold is not None and u is not None and z is not None
+    ref = u if u is not None else outputs.get('T', outputs.get('I_B0'))
+    n = int(ref.shape[0]) if ref.dim() > 0 else 1
+    with torch.cuda.device(dev):
+        T = m.dev_flat(outputs['T'], (n,), dev) if outputs.get('T') is not None else None
+        IB = m.dev_flat(outputs['I_B0'], (n,), dev) if outputs.get('I_B0') is not None else None
+        ncells = int(u.shape[-1]) if use_shock else 0
+        uu = u.to(device=dev, dtype=torch.float64).contiguous().reshape(n, ncells) if use_shock else None
+        zz = m.dev_flat(z, (ncells,), dev) if use_shock else None
+        flags = torch.empty(n, dtype=torch.uint8, device=dev)
+        _lib.check(lib.pem_thruster_filter_f64_dev(n, ncells, m.t_ptr(uu), m.t_ptr(zz),
+                                                    float(shock_threshold) if use_shock else 0.0, int(use_shock),
+                                                    m.t_ptr(T), m.t_ptr(IB), m.t_ptr(flags), m.current_stream_ptr(dev)))
+    return flags != 0
+
+
 _IN = ('V_a', 'V_cc', 'mdot_a', 'a_1')
 _OUT = ('I_B0', 'I_d', 'T', 'eta_c', 'eta_m', 'eta_v', 'eta_a', 'v_exh')
 
 
-def thruster_analytic(inputs: dict) -> dict:
+def thruster_analytic(inputs: dict, num_cells: int | None = None, domain=(0.0, 0.08)) -> dict:
     """Closed-form thruster stage of tests/sim_hallthruster.jl:35-48, batched on the GPU (a test double).
 
     :param inputs: `V_a` (V), `V_cc` (V), `mdot_a` (kg/s), `a_1` (the script's anom_model c1).
+    :param num_cells: if given, also return the ion velocity profile `u_ion` (..., num_cells) on
+                      `u_ion_coords` = range(domain[0], domain[1], length=num_cells) (script lines 46-47).
     :returns: `I_B0`, `I_d`, `T`, `eta_c`, `eta_m`, `eta_v`, `eta_a`, `v_exh`, each over the loop shape.
     """
     vals = [inputs[k] for k in _IN]
     lib = _lib.load()
     shape = m.loop_shape(vals)
     n = int(np.prod(shape))
-    if m.any_device_tensor(vals):
-        import torch
+    import torch
+    on_device = m.any_device_tensor(vals)
+    if on_device:
         dev = m.pick_device(vals)
         with torch.cuda.device(dev):
             flat = [m.dev_flat(v, shape, dev) for v in vals]
             outs = [torch.empty(n, dtype=torch.float64, device=dev) for _ in _OUT]
             _lib.check(lib.pem_thruster_f64_dev(n, *[m.t_ptr(t) for t in flat], *[m.t_ptr(t) for t in outs],
                                                 m.current_stream_ptr(dev)))
-        return {k: o.reshape(shape) for k, o in zip(_OUT, outs)}
-    flat = [m.host_flat(v, shape) for v in vals]
-    outs = [np.empty(n, dtype=np.float64) for _ in _OUT]
-    _lib.check(lib.pem_thruster_f64(n, *[m.np_ptr(a) for a in flat], *[m.np_ptr(a) for a in outs]))
-    return {k: o.reshape(shape) for k, o in zip(_OUT, outs)}
+        ret = {k: o.reshape(shape) for k, o in zip(_OUT, outs)}
+    else:
+        flat = [m.host_flat(v, shape) for v in vals]
+        outs = [np.empty(n, dtype=np.float64) for _ in _OUT]
+        _lib.check(lib.pem_thruster_f64(n, *[m.np_ptr(a) for a in flat], *[m.np_ptr(a) for a in outs]))
+        ret = {k: o.reshape(shape) for k, o in zip(_OUT, outs)}
+    if num_cells is not None:
+        _lib.require_device()
+        dev = m.pick_device(vals) if on_device else torch.device('cuda', torch.cuda.current_device())
+        with torch.cuda.device(dev):
+            v = m.dev_flat(ret['v_exh'], shape, dev)
+            z = torch.empty(int(num_cells), dtype=torch.float64, device=dev)
+            u = torch.empty((n, int(num_cells)), dtype=torch.float64, device=dev)
+            _lib.check(lib.pem_thruster_uion_f64_dev(n, m.t_ptr(v), float(domain[0]), float(domain[1]), int(num_cells),
+                                                      m.t_ptr(z), m.t_ptr(u), m.current_stream_ptr(dev)))
+        u = u.reshape(shape + (int(num_cells),))
+        ret['u_ion'] = u if on_device else u.cpu().numpy()
+        ret['u_ion_coords'] = z if on_device else z.cpu().numpy()
+    return ret

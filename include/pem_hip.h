@@ -96,6 +96,17 @@ int pem_thruster_f64(size_t n, const double* V_a, const double* V_cc, const doub
                      const double* a_1, double* I_B0, double* I_d, double* T, double* eta_c,
                      double* eta_m, double* eta_v, double* eta_a, double* v_exh);
 
+/* u_ion(z) = v_exh / (1 + exp(-100 (z - 0.04))) on z = range(z0, z1, length = ncells)  (sim_hallthruster.jl:46-47).
+ * z: [ncells] device array or NULL; u_ion: [n][ncells].                                               */
+int pem_thruster_uion_f64_dev(size_t n, const double* v_exh, double z0, double z1, int ncells, double* z,
+                              double* u_ion, pem_stream_t stream);
+/* The two post-run filters of hallthruster_jl (thruster.py:490-502), batched.  flags[i] bit 0: T < 0 or
+ * I_B0 < 0 (the reference raises "non-physical case"); bit 1 (only if use_shock): z[argmax(u_ion[i])] <
+ * shock_threshold (the reference raises "shock-like behavior").  T / I_B0 may be NULL (treated as 0).  */
+int pem_thruster_filter_f64_dev(size_t n, int ncells, const double* u_ion, const double* z, double shock_threshold,
+                                int use_shock, const double* T, const double* I_B0, uint8_t* flags,
+                                pem_stream_t stream);
+
 /* ---- coupled cathode -> thruster -> plume, one pass, sweep radius `radius` (R = 1) -----------
  * 15 inputs per sample; outputs V_cc, div_angle, T_c always; I_B0, T, invalid optional (NULL);
  * j_ion optional: NULL selects the reduced-QoI mode that never writes the 91-point profile.    */

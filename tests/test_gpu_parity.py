@@ -262,3 +262,33 @@ def test_mixed_precision_profile_tolerance(pem, oc):
     assert torch.equal(full.j_ion.float(), mixed.j_ion)                 # exactly the correctly rounded fp64 value
     rel = ((mixed.j_ion.double() - full.j_ion) / full.j_ion).abs()
     assert float(rel.max()) <= 2.0 ** -24 and float(rel.flatten().kthvalue(int(0.999 * rel.numel())).values) <= 2.0 ** -24
+
+
+# ---------------------------------------------------------------------------------------------- thruster profile + filters
+def test_thruster_profile_and_filters_on_device(pem, oc):
+    import torch
+    from hallthrusterpem_amd.models.thruster import check_thruster_outputs, thruster_analytic
+    x = coupled_inputs(3000, seed=31)
+    vcc = np.random.default_rng(32).uniform(0, 60, 3000)
+    ins = {'V_a': x['V_a'], 'V_cc': vcc, 'mdot_a': x['mdot_a'], 'a_1': x['a_1']}
+    host = thruster_analytic(ins, num_cells=102)                                 # tests/test_thruster.py:185 sizes
+    dev = thruster_analytic({k: torch.from_numpy(v).cuda() for k, v in ins.items()}, num_cells=102)
+    z, u = oc.thruster_uion(host['v_exh'], 0.0, 0.08, 102)
+    assert host['u_ion'].shape == (3000, 102) and rel_err(host['u_ion'], u) <= 1e-14
+    assert np.allclose(host['u_ion_coords'], z, rtol=4e-16, atol=0)
+    assert np.array_equal(dev['u_ion'].cpu().numpy(), host['u_ion'])
+    # filters: device result == numpy result == what the reference would raise for
+    T = host['T'].copy()
+    IB = host['I_B0'].copy()
+    T[5], IB[7] = -1e-3, -0.5
+    uu = host['u_ion'].copy()
+    uu[11, :20] = 1e9                                   # peak at z < threshold -> shock-like
+    uu[12, 40] = np.nan                                 # np.argmax lands on the NaN (z = 0.0317 < 0.04)
+    uu[13, 90] = np.nan                                 # NaN beyond the threshold
+    outs = {'T': T, 'I_B0': IB, 'u_ion': uu, 'u_ion_coords': host['u_ion_coords']}
+    bad_h = check_thruster_outputs(outs, shock_threshold=0.04)
+    bad_d = check_thruster_outputs({k: torch.from_numpy(v).cuda() for k, v in outs.items()}, shock_threshold=0.04)
+    assert bad_d.is_cuda and np.array_equal(bad_d.cpu().numpy(), bad_h)
+    assert bad_h[[5, 7, 11, 12]].all() and not bad_h[13] and bad_h.sum() == 4
+    no_shock = check_thruster_outputs({'T': torch.from_numpy(T).cuda(), 'I_B0': torch.from_numpy(IB).cuda()})
+    assert int(no_shock.sum()) == 2
