@@ -157,6 +157,23 @@ int pem_sample_lhs_f64_dev(size_t n, uint64_t first_index, uint64_t n_total, uin
                            int ndim, const int32_t* kind, const double* a, const double* b, double* out,
                            size_t ld, pem_stream_t stream);
 
+/* ---- SVD compression / reconstruction of field QoIs (fp64 MFMA) --------------------------------
+ * Stand in for amisc `Compression(method='svd')` on `j_ion` (norm log10) and `u_ion` (norm linear(1e-3)):
+ * scripts/pem_v0/pem_v0_SPT-100.yml:207-214,273-280, scripts/gen_data.py:261-294.  Third-party in the
+ * reference: parity UNPINNED; formulas (csrc/pem_svd.hip):
+ *     latent[n][rank] = norm(field[n][dof]) @ basis[dof][rank]        (compress)
+ *     field[n][dof]   = denorm(latent[n][rank] @ basis[dof][rank]^T)  (reconstruct)
+ * norm: PEM_NORM_NONE x; PEM_NORM_LOG10 log10(x) / 10^y; PEM_NORM_LINEAR x*norm_scale / y/norm_scale.
+ * All arrays row-major in device memory; dof <= PEM_SVD_MAX_DOF, rank <= 16.                          */
+#define PEM_SVD_MAX_DOF 208
+#define PEM_NORM_NONE 0
+#define PEM_NORM_LOG10 1
+#define PEM_NORM_LINEAR 2
+int pem_svd_compress_f64_dev(size_t n, int dof, int rank, int norm, double norm_scale, const double* field,
+                             const double* basis, double* latent, pem_stream_t stream);
+int pem_svd_reconstruct_f64_dev(size_t n, int dof, int rank, int norm, double norm_scale, const double* latent,
+                                const double* basis, double* field, pem_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
