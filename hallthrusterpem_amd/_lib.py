@@ -87,11 +87,12 @@ def load():
     with _lock:
         if _lib is not None:
             return _lib
-        if not LIB_PATH.exists():
+        path = Path(os.environ.get('PEM_HIP_LIB', LIB_PATH))      # PEM_HIP_LIB: experimental builds (tools/build_variant.sh)
+        if not path.exists():
             from . import build as _build
             _build.build()
         _hip_runtime = _share_torch_hip_runtime()
-        lib = C.CDLL(str(LIB_PATH))
+        lib = C.CDLL(str(path))
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)     # AttributeError here = the library does not match the header
             fn.restype = res

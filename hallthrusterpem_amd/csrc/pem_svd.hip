@@ -9,9 +9,14 @@
 // with norm/denorm = identity, log10 / 10^x, or scale s / 1/s -- and are checked against numpy matmul in fp64.
 //
 // These are the only GEMM-shaped pieces of the path: tall-skinny, K or N = dof <= 208,
-// the other dimension r <= 16, so they stream `field` once and are HBM-bound; the products run on
-// v_mfma_f64_16x16x4_f64 (D[16x16] += A[16x4] B[4x16]; lane l holds A[l&15][l>>4], B[l>>4][l&15] and
-// D[(l>>4) + 4 i][l&15], i = 0..3 -- MI355X guide section 3, the f64 map differs from the f32/bf16 one).
+// the other dimension r <= 16, so they stream `field` once and are HBM-bound.
+//   reconstruct: v_mfma_f64_16x16x4_f64 (D[16x16] += A[16x4] B[4x16]; lane l holds A[l&15][l>>4],
+//                B[l>>4][l&15] and D[(l>>4) + 4 i][l&15], i = 0..3 -- the f64 map differs from the f32/bf16 one).
+//   compress:    fp64 VALU.  Measured on MI355X (tools/microbench/mfma_f64_rate.hip): v_mfma_f64_16x16x4_f64 issues
+//                every 147 cycles per SIMD = 14 flop/clk/SIMD (~33 TFLOP/s chip), v_fma_f64 every 7.5 cycles
+//                with one wave per SIMD = 17 flop/clk/SIMD and twice that with two.  The MFMA form also pads r to
+//                16 columns; with r = 6 it needs 2.7x the flops at a lower rate and ran at 2.3 TB/s, so the
+//                compress product uses FMAs (lanes = 16 samples x 4 interleaved k-slices, shuffle-reduced).
 // A wave owns 16 consecutive samples per tile; their dof values are one contiguous block of `field`, moved
 // between HBM and LDS with 16-byte-per-lane accesses, exactly like the profile stores of pem_kernels.hip.
 #include <hip/hip_runtime.h>
@@ -31,11 +36,19 @@ constexpr int DOF_MAX = PEM_SVD_MAX_DOF;
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ double norm_fwd(int mode, double scale, double x) {
-    return mode == PEM_NORM_LOG10 ? log10(x) : (mode == PEM_NORM_LINEAR ? x * scale : x);
+// MODE is a template parameter: as a run-time value hipcc evaluates log10()/exp10() for every element and selects
+// afterwards (the "none" mode then ran no faster than it would with the transcendental in it).
+template <int MODE>
+__device__ __forceinline__ double norm_fwd(double scale, double x) {
+    if constexpr (MODE == PEM_NORM_LOG10) return log10(x);
+    else if constexpr (MODE == PEM_NORM_LINEAR) return x * scale;
+    else return x;
 }
-__device__ __forceinline__ double norm_inv(int mode, double scale, double y) {
-    return mode == PEM_NORM_LOG10 ? exp10(y) : (mode == PEM_NORM_LINEAR ? y / scale : y);
+template <int MODE>
+__device__ __forceinline__ double norm_inv(double scale, double y) {
+    if constexpr (MODE == PEM_NORM_LOG10) return exp10(y);
+    else if constexpr (MODE == PEM_NORM_LINEAR) return y / scale;
+    else return y;
 }
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -43,8 +56,13 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-// LDS: basis_p[ksteps*4][16] (zero padded) | per wave: tile[16*dof] (+2 slack)
-__global__ __launch_bounds__(BLOCK) void svd_compress_kernel(long long n, int dof, int r, int mode, double scale,
+// LDS: basis_p[ksteps*4][16] (zero padded) | per wave: tile[16*dof] + 4 zeroed slack doubles
+// UN = 16-byte pieces per lane of one 16-sample tile (ceil(8*dof/64)); the pieces of the NEXT tile are loaded into
+// registers while the current tile is multiplied.  RT = latent columns computed (>= rank, zero-padded basis).
+// Index arithmetic is kept 32-bit and out of the inner loops: the first version spent 1740 VALU instructions per
+// 16-sample tile, most of them 64-bit address math (rocprofv3 SQ_INSTS_VALU), and ran at 2.3 TB/s.
+template <int UN, int RT, int MODE>
+__global__ __launch_bounds__(BLOCK) void svd_compress_kernel(long long n, int dof, int r, double scale,
                                                              const double* __restrict__ field,
                                                              const double* __restrict__ basis,
                                                              double* __restrict__ latent) {
@@ -52,59 +70,109 @@ __global__ __launch_bounds__(BLOCK) void svd_compress_kernel(long long n, int do
     double* lds = reinterpret_cast<double*>(smem_raw);
     const int ksteps = (dof + 3) / 4;
     double* basis_p = lds;                                   // [ksteps*4][16]
-    const int tile_doubles = (16 * dof + 3) & ~1;
+    const int tile_doubles = (16 * dof + 5) & ~1;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    double* tile = lds + ksteps * 64 + wave * tile_doubles;  // [16][dof]
+    double* tile = lds + ksteps * 64 + wave * tile_doubles;  // [16][dof] + slack
     for (int i = tid; i < ksteps * 64; i += BLOCK) {
         const int k = i >> 4, c = i & 15;
         basis_p[i] = (k < dof && c < r) ? basis[(size_t)k * r + c] : 0.0;
     }
+    if (lane < 4) tile[16 * dof + lane] = 0.0;               // read (times a zero basis row) by the last k-step
     __syncthreads();
 
     const int row = lane & 15, quad = lane >> 4;
+    const int tile_len = 16 * dof;                            // doubles per full tile
     const long long ntiles = (n + 15) / 16;
     const long long stride = (long long)gridDim.x * WAVES;
-    for (long long t = (long long)blockIdx.x * WAVES + wave; t < ntiles; t += stride) {
-        const long long s0 = t * 16;
-        long long valid = (n - s0) * dof;                     // values of this tile that exist
-        if (valid > 16LL * dof) valid = 16LL * dof;
-        const double* src = field + s0 * dof;
-        // HBM -> LDS, normalising on the way; 16-byte pieces when the tile base is 16-byte aligned
-        if ((((uintptr_t)src) & 15) == 0) {
-            const int pieces = (int)(valid >> 1);
-            const f64x2* src2 = reinterpret_cast<const f64x2*>(src);
-            for (int i = lane; i < pieces; i += 64) {
-                const f64x2 v = __builtin_nontemporal_load(src2 + i);
-                tile[2 * i] = norm_fwd(mode, scale, v.x);
-                tile[2 * i + 1] = norm_fwd(mode, scale, v.y);
+    const bool vec_ok = (((uintptr_t)field) & 15) == 0;       // tiles start at multiples of 16*dof*8 bytes
+
+    // `len` = doubles of the tile that exist (tile_len except for the last tile of the batch)
+    auto fetch = [&](const double* tp, int len, f64x2 (&v)[UN]) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int i = 2 * (u * 64 + lane);
+            if (vec_ok && i + 1 < len) {
+                v[u] = *reinterpret_cast<const f64x2*>(tp + i);
+            } else {
+                v[u].x = i < len ? tp[i] : 1.0;
+                v[u].y = i + 1 < len ? tp[i + 1] : 1.0;
             }
-            if ((valid & 1) && lane == 0) tile[valid - 1] = norm_fwd(mode, scale, src[valid - 1]);
-        } else {
-            for (int i = lane; i < (int)valid; i += 64) tile[i] = norm_fwd(mode, scale, src[i]);
         }
-        for (int i = (int)valid + lane; i < 16 * dof; i += 64) tile[i] = 0.0;   // rows past the end of the batch
+    };
+    auto tile_length = [&](long long t) {
+        const long long rest = (n - t * 16) * dof;
+        return rest < tile_len ? (int)rest : tile_len;
+    };
+
+    // Two tiles are kept in flight in registers beyond the one in LDS: with one, the bytes in flight per CU are
+    // bounded by the LDS tiles (8 waves x 12 KB) and the read stream ran at 2.6 TB/s; with two 4.2 TB/s (232 us per
+    // 1.25e6 x 91 batch); with three the 232 VGPRs cost more than the extra bytes in flight bring (265 us).
+    long long t = (long long)blockIdx.x * WAVES + wave;
+    f64x2 nxt[UN], nxt2[UN];
+    if (t < ntiles) fetch(field + t * tile_len, tile_length(t), nxt);
+    if (t + stride < ntiles) fetch(field + (t + stride) * tile_len, tile_length(t + stride), nxt2);
+    const double* a_base = tile + row * dof + quad;
+    const f64x2* b_base = reinterpret_cast<const f64x2*>(basis_p + quad * 16);
+    for (; t < ntiles; t += stride) {
+        const int len = tile_length(t);
+        // registers -> LDS with the variable's norm applied; entries past the end of the batch become 0
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int i = 2 * (u * 64 + lane);
+            if (i < tile_len) {
+                f64x2 w;
+                w.x = i < len ? norm_fwd<MODE>(scale, nxt[u].x) : 0.0;
+                w.y = i + 1 < len ? norm_fwd<MODE>(scale, nxt[u].y) : 0.0;
+                *reinterpret_cast<f64x2*>(tile + i) = w;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) nxt[u] = nxt2[u];
+        if (t + 2 * stride < ntiles) fetch(field + (t + 2 * stride) * tile_len, tile_length(t + 2 * stride), nxt2);
         wave_lds_sync();
 
-        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-        for (int step = 0; step < ksteps; ++step) {
-            const int k = 4 * step + quad;
-            const double a = k < dof ? tile[row * dof + k] : 0.0;       // A[sample row][k]
-            const double b = basis_p[k * 16 + row];                      // B[k][column = lane & 15]
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-        }
-        // D[(quad + 4 i)][col = lane & 15]
-        const int col = row;
+        // lane (row = sample, quad): partial dot products over k = quad, quad + 4, ... for RT latent columns
+        double acc[RT];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const long long smp = s0 + quad + 4 * i;
-            if (col < r && smp < n) latent[smp * r + col] = acc[i];
+        for (int j = 0; j < RT; ++j) acc[j] = 0.0;
+        const double* ap = a_base;
+        const f64x2* bp = b_base;
+#pragma unroll 4
+        for (int step = 0; step < ksteps; ++step) {
+            const double a = *ap;             // k >= dof only in the last step: next row / zeroed slack, times a zero row
+            ap += 4;
+#pragma unroll
+            for (int j = 0; j < RT; j += 2) {
+                const f64x2 b = bp[j >> 1];
+                acc[j] = fma(a, b.x, acc[j]);
+                if (j + 1 < RT) acc[j + 1] = fma(a, b.y, acc[j + 1]);
+            }
+            bp += 32;                         // 4 basis rows of 16 doubles
+        }
+#pragma unroll
+        for (int j = 0; j < RT; ++j) {
+            acc[j] += __shfl_xor(acc[j], 16);
+            acc[j] += __shfl_xor(acc[j], 32);
+        }
+        // every quad now holds the full sums.  The tile's 16 x r latents are one contiguous block of `latent`:
+        // gather them in LDS (the tile is consumed) and store them with consecutive lanes.
+        wave_lds_sync();
+#pragma unroll
+        for (int j = 0; j < RT; ++j)
+            if ((j & 3) == quad && j < r) tile[row * r + j] = acc[j];
+        wave_lds_sync();
+        {
+            double* out = latent + t * 16 * r;
+            const int count = (len / dof) * r;
+            for (int e = lane; e < count; e += 64) out[e] = tile[e];
         }
         wave_lds_sync();
     }
 }
 
 // LDS: basis_t[16][dof_p] with dof_p = 16*ceil(dof/16) (zero padded) | per wave: tile[16*dof] (+2)
-__global__ __launch_bounds__(BLOCK) void svd_reconstruct_kernel(long long n, int dof, int r, int mode, double scale,
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void svd_reconstruct_kernel(long long n, int dof, int r, double scale,
                                                                 const double* __restrict__ latent,
                                                                 const double* __restrict__ basis,
                                                                 double* __restrict__ field) {
@@ -156,13 +224,13 @@ __global__ __launch_bounds__(BLOCK) void svd_reconstruct_kernel(long long n, int
             f64x2* dst2 = reinterpret_cast<f64x2*>(dst);
             for (int i = lane; i < pieces; i += 64) {
                 f64x2 v;
-                v.x = norm_inv(mode, scale, tile[2 * i]);
-                v.y = norm_inv(mode, scale, tile[2 * i + 1]);
+                v.x = norm_inv<MODE>(scale, tile[2 * i]);
+                v.y = norm_inv<MODE>(scale, tile[2 * i + 1]);
                 __builtin_nontemporal_store(v, dst2 + i);
             }
-            if ((valid & 1) && lane == 0) dst[valid - 1] = norm_inv(mode, scale, tile[valid - 1]);
+            if ((valid & 1) && lane == 0) dst[valid - 1] = norm_inv<MODE>(scale, tile[valid - 1]);
         } else {
-            for (int i = lane; i < (int)valid; i += 64) dst[i] = norm_inv(mode, scale, tile[i]);
+            for (int i = lane; i < (int)valid; i += 64) dst[i] = norm_inv<MODE>(scale, tile[i]);
         }
         wave_lds_sync();
     }
@@ -191,12 +259,30 @@ int pem_svd_compress_f64_dev(size_t n, int dof, int rank, int norm, double norm_
     if (int rc = check_args("pem_svd_compress", n, dof, rank, norm, field, basis, latent)) return rc;
     if (n == 0) return PEM_OK;
     if (int rc = pem::check_device()) return rc;
-    const size_t lds = ((size_t)((dof + 3) / 4) * 64 + (size_t)WAVES * ((16 * dof + 3) & ~1)) * 8;
-    static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(svd_compress_kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    HIP_TRY(attr);
-    hipLaunchKernelGGL(svd_compress_kernel, dim3(grid_for(n)), dim3(BLOCK), lds, static_cast<hipStream_t>(stream),
-                       (long long)n, dof, rank, norm, norm_scale, field, basis, latent);
+    const size_t lds = ((size_t)((dof + 3) / 4) * 64 + (size_t)WAVES * ((16 * dof + 5) & ~1)) * 8;
+    // UN: 16-byte pieces per lane of a 16-sample tile (12 covers dof <= 96); RT: latent columns computed (>= rank)
+#define PEM_SVD_LAUNCH(UN_, RT_, MODE_)                                                                              \
+    do {                                                                                                             \
+        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(svd_compress_kernel<UN_, RT_, MODE_>), \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);        \
+        HIP_TRY(attr);                                                                                               \
+        hipLaunchKernelGGL((svd_compress_kernel<UN_, RT_, MODE_>), dim3(grid_for(n)), dim3(BLOCK), lds,              \
+                           static_cast<hipStream_t>(stream), (long long)n, dof, rank, norm_scale, field, basis, latent); \
+    } while (0)
+#define PEM_SVD_BY_MODE(UN_, RT_)                                                   \
+    do {                                                                            \
+        if (norm == PEM_NORM_LOG10) PEM_SVD_LAUNCH(UN_, RT_, PEM_NORM_LOG10);       \
+        else if (norm == PEM_NORM_LINEAR) PEM_SVD_LAUNCH(UN_, RT_, PEM_NORM_LINEAR); \
+        else PEM_SVD_LAUNCH(UN_, RT_, PEM_NORM_NONE);                                \
+    } while (0)
+    const int rt = rank <= 4 ? 4 : (rank <= 8 ? 8 : 16);
+    if (dof <= 96) {
+        if (rt == 4) PEM_SVD_BY_MODE(12, 4); else if (rt == 8) PEM_SVD_BY_MODE(12, 8); else PEM_SVD_BY_MODE(12, 16);
+    } else {
+        if (rt == 4) PEM_SVD_BY_MODE(26, 4); else if (rt == 8) PEM_SVD_BY_MODE(26, 8); else PEM_SVD_BY_MODE(26, 16);
+    }
+#undef PEM_SVD_BY_MODE
+#undef PEM_SVD_LAUNCH
     HIP_TRY(hipGetLastError());
     return PEM_OK;
 }
@@ -207,11 +293,18 @@ int pem_svd_reconstruct_f64_dev(size_t n, int dof, int rank, int norm, double no
     if (n == 0) return PEM_OK;
     if (int rc = pem::check_device()) return rc;
     const size_t lds = ((size_t)16 * (((dof + 15) / 16) * 16) + (size_t)WAVES * ((16 * dof + 3) & ~1)) * 8;
-    static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(svd_reconstruct_kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    HIP_TRY(attr);
-    hipLaunchKernelGGL(svd_reconstruct_kernel, dim3(grid_for(n)), dim3(BLOCK), lds, static_cast<hipStream_t>(stream),
-                       (long long)n, dof, rank, norm, norm_scale, latent, basis, field);
+#define PEM_SVD_RLAUNCH(MODE_)                                                                                       \
+    do {                                                                                                             \
+        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(svd_reconstruct_kernel<MODE_>),   \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);        \
+        HIP_TRY(attr);                                                                                               \
+        hipLaunchKernelGGL((svd_reconstruct_kernel<MODE_>), dim3(grid_for(n)), dim3(BLOCK), lds,                     \
+                           static_cast<hipStream_t>(stream), (long long)n, dof, rank, norm_scale, latent, basis, field); \
+    } while (0)
+    if (norm == PEM_NORM_LOG10) PEM_SVD_RLAUNCH(PEM_NORM_LOG10);
+    else if (norm == PEM_NORM_LINEAR) PEM_SVD_RLAUNCH(PEM_NORM_LINEAR);
+    else PEM_SVD_RLAUNCH(PEM_NORM_NONE);
+#undef PEM_SVD_RLAUNCH
     HIP_TRY(hipGetLastError());
     return PEM_OK;
 }
