@@ -214,16 +214,22 @@ __device__ __forceinline__ SampleIn<COUPLED> load_sample(const PlumeIO& io, cons
 //   COUPLED  cathode + thruster stages are evaluated in front of the plume (inputs from CoupledIO)
 //   JMODE    0: reduced-QoI mode, no profile;  1: stage and store the 91-point profile as fp64;
 //            2: mixed mode -- same fp64 arithmetic, profile rounded once to fp32 when it is staged
-// LDS map (doubles): simpson[96][2] | dpoly[32*12] | params[9][64] | partial[64*L][2] | tile[S*91] | 2 (sink)
-// The Simpson table is padded with zero weights to L*CH <= 96 entries so the angle loop needs no branch.
+// LDS map (doubles): shared by the workgroup: simpson[96][2] | dpoly[32*12];  per wave: params[NROWS][64] |
+// tile[S*91] | 2 (sink).  The Simpson table is padded with zero weights to L*CH <= 96 entries so the angle loop
+// needs no branch.  The den/num partial sums of a round reuse the rows of `params` that the round has consumed.
 // ---------------------------------------------------------------------------------------------
 constexpr int NPARAM = 9;   // X1 X2 jcex | r0 G E (beam 1) | r0 G E (beam 2)
 constexpr int NSIMP = 96;   // >= L*CH for L in {2, 4, 8}
+constexpr int WPB = 4;      // waves per workgroup (they share the two tables and nothing else)
+template <int L>
+constexpr int param_rows() { return 2 * L > NPARAM ? 2 * L : NPARAM; }
+constexpr int TABLE_DOUBLES = 2 * NSIMP + PEM_NDI * PEM_NDC;
 template <int L, int JMODE>
-constexpr int fast_lds_doubles() {
-    return 2 * NSIMP + PEM_NDI * PEM_NDC + NPARAM * WAVE + 2 * WAVE * L +
-           (JMODE == 1 ? (WAVE / L) * NANG + 2 : JMODE == 2 ? ((WAVE / L) * NANG + 4) / 2 : 0);
+constexpr int wave_lds_doubles() {
+    return param_rows<L>() * WAVE + (JMODE == 1 ? (WAVE / L) * NANG + 2 : JMODE == 2 ? ((WAVE / L) * NANG + 4) / 2 : 0);
 }
+template <int L, int JMODE>
+constexpr int fast_lds_doubles() { return TABLE_DOUBLES + WPB * wave_lds_doubles<L, JMODE>(); }
 
 // Order LDS traffic inside ONE wave (the workgroup is a single wave): the LDS unit executes a wave's
 // DS instructions in issue order, so only the compiler has to be kept from reordering them.
@@ -253,7 +259,6 @@ struct WaveLds {
     const double2* simpson;  // [96] {cden, cnum}
     const double* poly;      // [32*12]
     double* params;          // [9][64]
-    double2* partial;        // [64*L] {den, num}
     double* tile;            // [S*91] + 2
 };
 
@@ -374,7 +379,9 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
             X2 *= rr2;
             rr2 *= q2;
         }
-        m.partial[smp * L + c] = make_double2(den, num);
+        // this round has read its nine parameter rows of sample `smp`: rows 2c, 2c+1 now carry the partial sums
+        params[(2 * c) * WAVE + smp] = den;
+        params[(2 * c + 1) * WAVE + smp] = num;
         // plume.py:105: invalid if alpha1 <= 0 or any j_ion <= 0 (NaN compares false)
         unsigned long long bad = __ballot(lo <= 0.0);
 #pragma unroll
@@ -420,9 +427,8 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
     double den = 0.0, num = 0.0;
 #pragma unroll
     for (int i = 0; i < L; ++i) {
-        const double2 p = m.partial[lane * L + i];
-        den += p.x;
-        num += p.y;
+        den += params[(2 * i) * WAVE + lane];
+        num += params[(2 * i + 1) * WAVE + lane];
     }
     double cos_div = num / den;  // plume.py:124-127
     if (cos_div == __builtin_inf()) cos_div = __builtin_nan("");
@@ -436,28 +442,27 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
             if (cio.T) stream_store1(thrust, cio.T + g);
         }
     }
-    wave_lds_sync();  // params / partial are rewritten by the next tile
+    wave_lds_sync();  // params are rewritten by the next tile
 }
 
 template <int L, bool COUPLED, int JMODE>
-__global__ __launch_bounds__(WAVE) void plume_r1_kernel(PlumeIO io, CoupledIO cio, long long ntiles) {
+__global__ __launch_bounds__(WAVE * WPB) void plume_r1_kernel(PlumeIO io, CoupledIO cio, long long ntiles) {
     static_assert(L == 2 || L == 4 || L == 8, "lanes per sample");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* lds = reinterpret_cast<double*>(smem_raw);
     double2* tab_simpson = reinterpret_cast<double2*>(lds);          // [96] {cden, cnum}, zero past angle 90
     double* tab_poly = lds + 2 * NSIMP;                               // [32*12]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     WaveLds m;
     m.simpson = tab_simpson;
     m.poly = tab_poly;
-    m.params = tab_poly + PEM_NDI * PEM_NDC;                          // [9][64]
-    m.partial = reinterpret_cast<double2*>(m.params + NPARAM * WAVE); // [64*L]
-    m.tile = m.params + NPARAM * WAVE + 2 * WAVE * L;                 // [S*91] + 2
+    m.params = lds + TABLE_DOUBLES + wave * wave_lds_doubles<L, JMODE>();   // [rows][64], private to this wave
+    m.tile = m.params + param_rows<L>() * WAVE;                               // [S*91] + sink
 
-    const int lane = threadIdx.x;
-    for (int i = lane; i < NSIMP; i += WAVE)
+    for (int i = tid; i < NSIMP; i += WAVE * WPB)
         tab_simpson[i] = i < NANG ? make_double2(PEM_SIMPSON_CDEN[i], PEM_SIMPSON_CNUM[i]) : make_double2(0.0, 0.0);
-    for (int i = lane; i < PEM_NDI * PEM_NDC; i += WAVE) tab_poly[i] = PEM_DPOLY[i];
-    wave_lds_sync();
+    for (int i = tid; i < PEM_NDI * PEM_NDC; i += WAVE * WPB) tab_poly[i] = PEM_DPOLY[i];
+    __syncthreads();   // the only workgroup barrier: from here on the waves are independent
 
     const double rad = io.radius;
     const double inv_r2 = 1.0 / (rad * rad);
@@ -465,17 +470,18 @@ __global__ __launch_bounds__(WAVE) void plume_r1_kernel(PlumeIO io, CoupledIO ci
 
     // persistent loop over the tiles whose 64 samples all exist; inputs are prefetched one tile ahead
     const long long nfull = io.n / WAVE;
-    long long t = blockIdx.x;
+    const long long me = (long long)blockIdx.x * WPB + wave, nwaves = (long long)gridDim.x * WPB;
+    long long t = me;
     if (t < nfull) {
         SampleIn<COUPLED> nxt = load_sample<COUPLED>(io, cio, t * WAVE + lane);
-        for (; t < nfull; t += gridDim.x) {
+        for (; t < nfull; t += nwaves) {
             const SampleIn<COUPLED> in = nxt;
-            if (t + gridDim.x < nfull) nxt = load_sample<COUPLED>(io, cio, (t + gridDim.x) * WAVE + lane);
+            if (t + nwaves < nfull) nxt = load_sample<COUPLED>(io, cio, (t + nwaves) * WAVE + lane);
             process_tile<L, COUPLED, JMODE, true>(io, cio, m, in, t, lane, rad, inv_r2, inv_2pi_r2);
         }
     }
     // the ragged last tile (n % 64 samples) goes to the wave that would have been next in line for it
-    if (nfull < ntiles && (nfull % gridDim.x) == blockIdx.x) {
+    if (nfull < ntiles && (nfull % nwaves) == me) {
         const long long g = nfull * WAVE + lane;
         const SampleIn<COUPLED> in = load_sample<COUPLED>(io, cio, g < io.n ? g : io.n - 1);
         process_tile<L, COUPLED, JMODE, false>(io, cio, m, in, nfull, lane, rad, inv_r2, inv_2pi_r2);
@@ -654,25 +660,24 @@ std::once_flag g_grid_once;
 using pem::check_device;
 using pem::fail;
 
-// persistent grid of the fast kernel: as many single-wave workgroups as the LDS admits on every CU
+// persistent grid of the fast kernel: workgroups of WPB waves, as many as the LDS admits on every CU, capped at
+// two waves per SIMD
 int fast_grid(size_t lds_bytes, long long ntiles, unsigned* grid) {
     static int cus[64] = {0};
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return fail(PEM_ERR_INVALID_ARG, "device index %d out of range", dev);
     if (cus[dev] == 0) HIP_TRY(hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev));
-    // One wave per SIMD (4 per CU) is the measured optimum; a count that leaves the four SIMDs of a CU
-    // unevenly loaded (5 or 6 waves) is 8-10 % slower than 4 (tools/ab_bench.py sweep).
-    long long per_cu = (long long)(160 * 1024 / lds_bytes);
-    if (per_cu > 4) per_cu = 4 * (per_cu / 4);
-    if (per_cu > 4) per_cu = 4;
-    if (const char* e = getenv("PEM_WAVES_PER_CU")) {   // tuning/experiments only
-        const long long v = atoll(e);
+    long long per_cu = (long long)(160 * 1024 / lds_bytes);   // workgroups per CU
+    if (per_cu > 8 / WPB) per_cu = 8 / WPB;
+    if (const char* e = getenv("PEM_WAVES_PER_CU")) {          // tuning/experiments only
+        const long long v = atoll(e) / WPB;
         if (v >= 1 && v < per_cu) per_cu = v;
     }
     if (per_cu < 1) per_cu = 1;
     long long g = (long long)cus[dev] * per_cu;
-    if (g > ntiles) g = ntiles;
+    const long long need = (ntiles + WPB - 1) / WPB;
+    if (g > need) g = need;
     *grid = (unsigned)g;
     return PEM_OK;
 }
@@ -684,7 +689,12 @@ int launch_r1(const PlumeIO& io, const CoupledIO& cio, hipStream_t st) {
     unsigned grid = 0;
     if (int rc = fast_grid(lds, ntiles, &grid)) return rc;
     auto kern = plume_r1_kernel<L, COUPLED, JMODE>;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), lds, st, io, cio, ntiles);
+    if (lds > 64 * 1024) {
+        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        HIP_TRY(attr);
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * WPB), lds, st, io, cio, ntiles);
     HIP_TRY(hipGetLastError());
     return PEM_OK;
 }
