@@ -237,7 +237,7 @@ def main():
                        'invalid_fraction': frac_invalid},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel': 'plume_r1_kernel<L,COUPLED,WRITE_J>', 'kernel_ms_mean': kern_mean_ms,
+                         'kernel': 'plume_r1_kernel<L,COUPLED,JMODE>', 'kernel_ms_mean': kern_mean_ms,
                          'kernel_ms_min': kern_ms[0], 'bytes_per_eval': batch.bytes_per_eval,
                          'bytes_per_launch': bytes_per_launch},
         }

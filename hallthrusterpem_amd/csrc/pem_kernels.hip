@@ -8,7 +8,8 @@
 // Kernel shape (DESIGN.md holds the measurements behind each choice).  The path is a streaming map,
 // 120 B in and 752 B out per sample; the first version was VALU-bound on fp64 transcendentals
 // (1246 VALU instructions per 16 samples), so the design removes them until HBM writes are the bound:
-//   * One 64-lane wave (= one workgroup, persistent over tiles) owns 64 consecutive samples.
+//   * One 64-lane wave owns 64 consecutive samples per tile and is persistent over tiles; a workgroup is 4 such
+//     waves that share two LDS tables and nothing else (8 waves per CU).
 //   * PRELUDE, one lane per sample, nothing redundant: cathode + thruster stages, alpha1/alpha2, the two
 //     normalisers, beam amplitudes.  The normaliser D(a) = 2 pi Int_0^{pi/2} exp(-(t/a)^2) sin t dt
 //     (identical to the six complex erfi of plume.py:64-85) is a degree-11 polynomial in u = 1/a^2 from a
@@ -209,7 +210,7 @@ __device__ __forceinline__ SampleIn<COUPLED> load_sample(const PlumeIO& io, cons
 }
 
 // ---------------------------------------------------------------------------------------------
-// fast path: R = 1.  One wave per workgroup, persistent over 64-sample tiles.
+// fast path: R = 1.  Each wave is persistent over 64-sample tiles; WPB independent waves per workgroup.
 //   L        lanes that share a sample during the rounds (2, 4 or 8)
 //   COUPLED  cathode + thruster stages are evaluated in front of the plume (inputs from CoupledIO)
 //   JMODE    0: reduced-QoI mode, no profile;  1: stage and store the 91-point profile as fp64;
@@ -231,8 +232,8 @@ constexpr int wave_lds_doubles() {
 template <int L, int JMODE>
 constexpr int fast_lds_doubles() { return TABLE_DOUBLES + WPB * wave_lds_doubles<L, JMODE>(); }
 
-// Order LDS traffic inside ONE wave (the workgroup is a single wave): the LDS unit executes a wave's
-// DS instructions in issue order, so only the compiler has to be kept from reordering them.
+// Order LDS traffic inside ONE wave (after the table load a wave only ever reads LDS it wrote itself): the LDS
+// unit executes a wave's DS instructions in issue order, so only the compiler has to be kept from reordering them.
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
