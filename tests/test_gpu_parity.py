@@ -292,3 +292,69 @@ def test_thruster_profile_and_filters_on_device(pem, oc):
     assert bad_h[[5, 7, 11, 12]].all() and not bad_h[13] and bad_h.sum() == 4
     no_shock = check_thruster_outputs({'T': torch.from_numpy(T).cuda(), 'I_B0': torch.from_numpy(IB).cuda()})
     assert int(no_shock.sum()) == 2
+
+
+# ---------------------------------------------------------------------------------------------- C-ABI error behaviour
+def test_c_abi_argument_errors_and_fallback_paths(pem, oc):
+    """API misuse returns status codes with a message (never a crash); a misaligned j_ion falls back to the
+    general kernel and still matches."""
+    import ctypes as C
+    import torch
+    from hallthrusterpem_amd import _lib
+    lib = _lib.load()
+    x = plume_inputs(1000, seed=41)
+    d = {k: torch.from_numpy(v).cuda() for k, v in x.items()}
+    ptr = lambda t: C.c_void_p(t.data_ptr())                                          # noqa: E731
+    ins = [ptr(d[k]) for k in PLUME_KEYS]
+    j = torch.empty(1000 * 91 + 1, dtype=torch.float64, device='cuda')
+    div = torch.empty(1000, dtype=torch.float64, device='cuda')
+    tc = torch.empty(1000, dtype=torch.float64, device='cuda')
+    rad = np.array([1.0])
+    rp = C.c_void_p(rad.ctypes.data)
+    k = pem.constants.TORR_2_PA
+    # T without T_c
+    rc = lib.pem_plume_f64_dev(1000, 1, rp, k, *ins, ptr(d['T']), ptr(j), ptr(div), None, None, None)
+    assert rc == _lib.PEM_ERR_INVALID_ARG and b'T and T_c' in lib.pem_last_error()
+    # no radii / NULL arrays
+    assert lib.pem_plume_f64_dev(1000, 0, rp, k, *ins, None, ptr(j), ptr(div), None, None, None) == _lib.PEM_ERR_INVALID_ARG
+    assert lib.pem_plume_f64_dev(1000, 1, rp, k, None, *ins[1:], None, ptr(j), ptr(div), None, None, None) == _lib.PEM_ERR_INVALID_ARG
+    assert lib.pem_cathode_f64_dev(10, None, None, None, None, None, None, k, None, None) == _lib.PEM_ERR_INVALID_ARG
+    with pytest.raises(_lib.PemHipError):
+        _lib.check(_lib.PEM_ERR_INVALID_ARG)
+    # misaligned profile pointer (8 bytes off a 16-byte boundary): general kernel, same numbers
+    j_mis = j[1:]
+    assert j_mis.data_ptr() % 16 == 8
+    rc = lib.pem_plume_f64_dev(1000, 1, rp, k, *ins, ptr(d['T']), ptr(j_mis), ptr(div), ptr(tc), None, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    ref = oc.plume(*[x[kk] for kk in PLUME_KEYS], k, T=x['T'])
+    assert rel_err(j_mis.cpu().numpy().reshape(1000, 91), ref['j_ion'][:, :, 0]) <= RTOL
+    assert div_err(div.cpu().numpy(), ref['div_angle'][:, 0]) <= RTOL
+    # coupled insists on alignment (its profile stores are 16-byte pieces)
+    c = coupled_inputs(100, seed=42)
+    cd = [ptr(torch.from_numpy(c[kk]).cuda()) for kk in ('P_b', 'V_a', 'T_e', 'V_vac', 'Pstar', 'P_T', 'mdot_a', 'a_1',
+                                                          'c0', 'c1', 'c2', 'c3', 'c4', 'c5', 'sigma_cex')]
+    o = [torch.empty(100, dtype=torch.float64, device='cuda') for _ in range(5)]
+    rc = lib.pem_coupled_f64_dev(100, k, 1.0, *cd, ptr(o[0]), ptr(o[1]), ptr(o[2]), ptr(j_mis), ptr(o[3]), ptr(o[4]), None, None)
+    assert rc == _lib.PEM_ERR_INVALID_ARG and b'aligned' in lib.pem_last_error()
+    # lanes knob only accepts supported values
+    assert lib.pem_set_lanes_per_sample(3) == 4 and lib.pem_set_lanes_per_sample(2) == 2 and lib.pem_set_lanes_per_sample(0) == 4
+
+
+def test_large_batch_index_arithmetic(pem):
+    """2.5e7 samples in reduced-QoI mode (3.6 GB of inputs): 64-bit indexing, persistent loop over 390k tiles;
+    first / last / strided samples against a small evaluation of the same inputs."""
+    import torch
+    from hallthrusterpem_amd.batch import CoupledBatch
+    from hallthrusterpem_amd.sampling import Design
+    n = 25_000_007
+    big = CoupledBatch(n, profile=False)
+    Design(seed=77).fill(big.inputs)
+    big.run()
+    idx = torch.tensor([0, 1, 63, 64, 12_345_678, n - 65, n - 64, n - 2, n - 1], device='cuda')
+    small = CoupledBatch(idx.numel(), profile=False)
+    small.inputs.copy_(big.inputs[:, idx])
+    small.run()
+    torch.cuda.synchronize()
+    assert torch.equal(big.qoi[:, idx], small.qoi)
+    assert bool(torch.isfinite(big.qoi).all())
