@@ -8,6 +8,7 @@
 //     ll[i] = sum_a -0.5 * ((y[e][a] - J_i(|alpha[e][a]|)) * inv_std[e][a])^2 ,   e = i mod n_cond,
 //     J_i(x) = (1 - w) j_ion[i][k] + w j_ion[i][k+1],  k = floor(x / h), w = x / h - k,  h = (pi/2) / 90.
 // The host precomputes (k, w) per measurement; the kernel is one pass over j_ion (HBM-bound, 728 B per sample).
+// The (k, w, y, inv_std) tables (<= 4096 measurements, 28 bytes each) are staged in LDS.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -17,34 +18,97 @@
 
 namespace {
 
-constexpr int BLOCK = 256;
+constexpr int WAVES = 4;
+constexpr int BLOCK = 64 * WAVES;
+constexpr int NANG = PEM_NANGLE;
+constexpr int TILE = 16 * NANG;          // doubles of a 16-sample tile (contiguous in j_ion)
+constexpr int UN = (TILE / 2 + 63) / 64; // 16-byte pieces per lane (12)
 
-// 16 lanes per sample: lane q of a group takes measurements q, q+16, ...; DPP-sized xor reduction over the group
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// A wave owns 16 consecutive samples per tile: their 16 x 91 profile values are one contiguous block, moved to LDS
+// with 16-byte-per-lane loads (two tiles ahead in registers, as in svd_compress_kernel: a gather straight from
+// global memory ran at 3.7 TB/s).  Lane (s = lane & 15, q = lane >> 4) then takes measurements q, q+4, ... of sample s
+// from LDS; the four partial sums meet by shuffles.
 __global__ __launch_bounds__(BLOCK) void jion_loglik_kernel(long long n, int n_cond, int n_ang,
                                                             const int32_t* __restrict__ kidx,
                                                             const double* __restrict__ wgt, const double* __restrict__ y,
                                                             const double* __restrict__ inv_std,
                                                             const double* __restrict__ j_ion, double* __restrict__ ll) {
-    const int q = threadIdx.x & 15;
-    const long long group = ((long long)blockIdx.x * BLOCK + threadIdx.x) >> 4;
-    const long long ngroups = ((long long)gridDim.x * BLOCK) >> 4;
-    for (long long i = group; i < n; i += ngroups) {
-        const int e = (int)(i % n_cond);
-        const double* row = j_ion + i * PEM_NANGLE;
-        const int base = e * n_ang;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    double* tile = reinterpret_cast<double*>(smem_raw) + wave * (TILE + 2);
+    // measurement tables in LDS: vmcnt is one in-order counter, so a table load from global memory inside the
+    // loop would wait for every prefetched tile load issued before it (355 us per 1.25e6 samples that way)
+    const int nent = n_cond * n_ang;
+    double* tab_w = reinterpret_cast<double*>(smem_raw) + WAVES * (TILE + 2);
+    double* tab_y = tab_w + nent;
+    double* tab_is = tab_y + nent;
+    int32_t* tab_k = reinterpret_cast<int32_t*>(tab_is + nent);
+    for (int i = tid; i < nent; i += BLOCK) {
+        tab_w[i] = wgt[i];
+        tab_y[i] = y[i];
+        tab_is[i] = inv_std[i];
+        tab_k[i] = kidx[i];
+    }
+    __syncthreads();
+    const int s = lane & 15, q = lane >> 4;
+    const long long ntiles = (n + 15) / 16;
+    const long long stride = (long long)gridDim.x * WAVES;
+    const bool vec_ok = (((uintptr_t)j_ion) & 15) == 0;
+
+    auto fetch = [&](long long t, f64x2 (&v)[UN]) {
+        const double* tp = j_ion + t * TILE;
+        const long long rest = (n - t * 16) * NANG;
+        const int len = rest < TILE ? (int)rest : TILE;
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int i = 2 * (u * 64 + lane);
+            if (vec_ok && i + 1 < len) {
+                v[u] = *reinterpret_cast<const f64x2*>(tp + i);
+            } else {
+                v[u].x = i < len ? tp[i] : 0.0;
+                v[u].y = i + 1 < len ? tp[i + 1] : 0.0;
+            }
+        }
+    };
+
+    long long t = (long long)blockIdx.x * WAVES + wave;
+    f64x2 nxt[UN], nxt2[UN];
+    if (t < ntiles) fetch(t, nxt);
+    if (t + stride < ntiles) fetch(t + stride, nxt2);
+    for (; t < ntiles; t += stride) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int i = 2 * (u * 64 + lane);
+            if (i < TILE) *reinterpret_cast<f64x2*>(tile + i) = nxt[u];
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) nxt[u] = nxt2[u];
+        if (t + 2 * stride < ntiles) fetch(t + 2 * stride, nxt2);
+        wave_lds_sync();
+
+        const long long i = t * 16 + s;
+        const int base = (int)(i % n_cond) * n_ang;
+        const double* row = tile + s * NANG;
         double acc = 0.0;
-        for (int a = q; a < n_ang; a += 16) {
-            const int k = kidx[base + a];
-            const double w = wgt[base + a];
-            const double model = fma(w, row[k + 1] - row[k], row[k]);
-            const double z = (y[base + a] - model) * inv_std[base + a];
+        for (int a = q; a < n_ang; a += 4) {
+            const int k = tab_k[base + a];
+            const double w = tab_w[base + a];
+            const double lo = row[k], hi = row[k + 1];
+            const double model = fma(w, hi - lo, lo);
+            const double z = (tab_y[base + a] - model) * tab_is[base + a];
             acc = fma(-0.5 * z, z, acc);
         }
-        acc += __shfl_xor(acc, 1);
-        acc += __shfl_xor(acc, 2);
-        acc += __shfl_xor(acc, 4);
-        acc += __shfl_xor(acc, 8);
-        if (q == 0) ll[i] = acc;
+        acc += __shfl_xor(acc, 16);
+        acc += __shfl_xor(acc, 32);
+        if (q == 0 && i < n) ll[i] = acc;
+        wave_lds_sync();
     }
 }
 
@@ -57,9 +121,15 @@ extern "C" int pem_jion_loglik_f64_dev(size_t n, int n_cond, int n_ang, const in
     if (n == 0) return PEM_OK;
     if (!kidx || !weight || !y || !inv_std || !j_ion || !loglik) return pem::fail(PEM_ERR_INVALID_ARG, "pem_jion_loglik: NULL array");
     if (int rc = pem::check_device()) return rc;
-    size_t blocks = (n * 16 + BLOCK - 1) / BLOCK;
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(jion_loglik_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, static_cast<hipStream_t>(stream),
+    if ((long long)n_cond * n_ang > PEM_LOGLIK_MAX_MEASUREMENTS)
+        return pem::fail(PEM_ERR_INVALID_ARG, "pem_jion_loglik: more than %d measurements (n_cond * n_ang)", PEM_LOGLIK_MAX_MEASUREMENTS);
+    size_t blocks = ((n + 15) / 16 + WAVES - 1) / WAVES;
+    if (blocks > 256 * 2) blocks = 256 * 2;            // persistent: >= 47 KB of LDS per workgroup
+    const size_t lds = (size_t)WAVES * (TILE + 2) * 8 + (size_t)n_cond * n_ang * 28 + 16;
+    static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(jion_loglik_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    HIP_TRY(attr);
+    hipLaunchKernelGGL(jion_loglik_kernel, dim3((unsigned)blocks), dim3(BLOCK), lds, static_cast<hipStream_t>(stream),
                        (long long)n, n_cond, n_ang, kidx, weight, y, inv_std, j_ion, loglik);
     HIP_TRY(hipGetLastError());
     return PEM_OK;

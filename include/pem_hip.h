@@ -160,7 +160,9 @@ int pem_sample_lhs_f64_dev(size_t n, uint64_t first_index, uint64_t n_total, uin
 /* ---- likelihood of measured ion current density (scripts/pem_v0/mcmc.py:57-106, `jion` branch; the mirrored
  * linear interpolation of monte_carlo.py:265-270 / plume.py:142-149).  The scripts are stale and untested in the
  * reference: parity UNPINNED; formula in csrc/pem_likelihood.hip.  Sample i belongs to condition i mod n_cond.
- * kidx/weight/y/inv_std: [n_cond][n_ang] device arrays (k in [0, 89], weight in [0, 1]); loglik: [n].          */
+ * kidx/weight/y/inv_std: [n_cond][n_ang] device arrays (k in [0, 89], weight in [0, 1]), at most
+ * PEM_LOGLIK_MAX_MEASUREMENTS entries; loglik: [n].                                                          */
+#define PEM_LOGLIK_MAX_MEASUREMENTS 4096
 int pem_jion_loglik_f64_dev(size_t n, int n_cond, int n_ang, const int32_t* kidx, const double* weight,
                             const double* y, const double* inv_std, const double* j_ion, double* loglik,
                             pem_stream_t stream);
