@@ -143,14 +143,15 @@ def main():
     _lib.require_device()
     lanes = lib.pem_set_lanes_per_sample(args.lanes)
     n = args.samples_per_gpu
-    batch = CoupledBatch(n, profile=not args.no_profile, mixed=args.mixed)
+    # outputs per evaluation exactly as SURVEY section 8d counts them: V_cc, j_ion[91], div_angle, T_c (+ invalid flag)
+    batch = CoupledBatch(n, profile=not args.no_profile, mixed=args.mixed, thruster_qoi=False)
     synth_inputs(batch, args.seed, rank)
     # N > 1: the all-gather of step i runs beside the evaluation of step i+1 (RCCL works on its own stream):
     # two batches alternate so a QoI buffer is not rewritten while it is still being sent.
     nbuf = 2 if (world > 1 and args.gather != 'none') else 1
     batches = [batch]
     for _ in range(nbuf - 1):
-        b2 = CoupledBatch(n, profile=not args.no_profile, mixed=args.mixed)
+        b2 = CoupledBatch(n, profile=not args.no_profile, mixed=args.mixed, thruster_qoi=False)
         b2.inputs.copy_(batch.inputs)
         batches.append(b2)
     gathered, pending = [], [None] * nbuf

@@ -20,7 +20,8 @@ BYTES_PER_EVAL_CATHODE = 7 * 8                                  # 56
 
 
 class CoupledBatch:
-    def __init__(self, n: int, device=None, profile: bool = True, sweep_radius: float = 1.0, mixed: bool = False):
+    def __init__(self, n: int, device=None, profile: bool = True, sweep_radius: float = 1.0, mixed: bool = False,
+                 thruster_qoi: bool = True):
         import torch
         _lib.load()
         _lib.require_device()
@@ -32,8 +33,9 @@ class CoupledBatch:
         f64 = dict(dtype=torch.float64, device=self.device)
         self.inputs = torch.empty((len(COUPLED_INPUTS), self.n), **f64)         # SoA: one row per variable
         self.qoi = torch.empty((len(QOI_NAMES), self.n), **f64)                  # V_cc, div_angle, T_c
-        self.I_B0 = torch.empty(self.n, **f64)
-        self.T = torch.empty(self.n, **f64)
+        # the coupling variables I_B0 / T are optional outputs (not among SURVEY section 8d's 872 bytes per evaluation)
+        self.I_B0 = torch.empty(self.n, **f64) if thruster_qoi else None
+        self.T = torch.empty(self.n, **f64) if thruster_qoi else None
         self.j_ion = (torch.empty((self.n, _lib.NANGLE), dtype=torch.float32 if self.mixed else torch.float64,
                                   device=self.device) if self.profile else None)
         self.invalid = torch.empty(self.n, dtype=torch.uint8, device=self.device)
@@ -42,7 +44,8 @@ class CoupledBatch:
     def _bind(self):
         p = lambda t: C.c_void_p(t.data_ptr())                                   # noqa: E731
         self._in_ptrs = [p(self.inputs[i]) for i in range(len(COUPLED_INPUTS))]
-        self._out_ptrs = [p(self.qoi[0]), p(self.I_B0), p(self.T), p(self.j_ion) if self.profile else None,
+        self._out_ptrs = [p(self.qoi[0]), p(self.I_B0) if self.I_B0 is not None else None,
+                          p(self.T) if self.T is not None else None, p(self.j_ion) if self.profile else None,
                           p(self.qoi[1]), p(self.qoi[2]), p(self.invalid)]
 
     def set_inputs(self, values: dict):
@@ -60,8 +63,9 @@ class CoupledBatch:
         _lib.check(rc)
 
     def outputs(self) -> dict:
-        out = {'V_cc': self.qoi[0], 'div_angle': self.qoi[1], 'T_c': self.qoi[2], 'I_B0': self.I_B0, 'T': self.T,
-               'invalid': self.invalid.bool()}
+        out = {'V_cc': self.qoi[0], 'div_angle': self.qoi[1], 'T_c': self.qoi[2], 'invalid': self.invalid.bool()}
+        if self.I_B0 is not None:
+            out['I_B0'], out['T'] = self.I_B0, self.T
         if self.profile:
             out['j_ion'] = self.j_ion
         return out
