@@ -38,6 +38,7 @@
 
 #include "pem_common.h"
 #include "pem_hip.h"
+#include "pem_philox.h"
 
 #define PEM_TABLE_DECL static __device__ const
 #include "pem_tables.h"
@@ -158,6 +159,18 @@ struct CoupledIO {
     double *V_cc, *I_B0, *T;
 };
 
+// fused Monte-Carlo mode: the 15 coupled inputs are generated in registers from the counter-based design instead
+// of being read from HBM (order of COUPLED inputs: P_b V_a T_e V_vac Pstar P_T mdot_a a_1 c0..c5 sigma_cex)
+struct McDesign {
+    unsigned long long seed, first;
+    unsigned int stream;
+    int enabled;
+    int kind[15];
+    double a[15], b[15];
+    double* x_out;          // optional [15][ld] copy of the generated inputs
+    unsigned long long ld;
+};
+
 // the per-sample inputs of one lane, prefetched one tile ahead
 template <bool COUPLED>
 struct SampleIn {
@@ -206,6 +219,28 @@ __device__ __forceinline__ SampleIn<COUPLED> load_sample(const PlumeIO& io, cons
         v.x1 = io.T ? stream_load(io.T + gi) : 0.0;
         v.x2 = v.x3 = v.x4 = v.x5 = v.x6 = 0.0;
     }
+    return v;
+}
+
+// inputs of global sample `g` from the design: bit-identical to pem_sample_f64_dev followed by a load
+__device__ __forceinline__ SampleIn<true> generate_sample(const McDesign& mc, long long g_local) {
+    const unsigned long long g = mc.first + (unsigned long long)g_local;
+    const unsigned int k0 = (unsigned int)mc.seed, k1 = (unsigned int)(mc.seed >> 32);
+    double x[16];
+#pragma unroll
+    for (int pair = 0; pair < 8; ++pair) {
+        const pem::Philox4 r = pem::philox4x32_10((unsigned int)g, (unsigned int)(g >> 32), (unsigned int)pair, mc.stream, k0, k1);
+        x[2 * pair] = pem::transform(mc.kind[2 * pair], mc.a[2 * pair], mc.b[2 * pair], pem::u53(r.x, r.y));
+        if (2 * pair + 1 < 15)
+            x[2 * pair + 1] = pem::transform(mc.kind[2 * pair + 1], mc.a[2 * pair + 1], mc.b[2 * pair + 1], pem::u53(r.z, r.w));
+    }
+    if (mc.x_out) {
+#pragma unroll
+        for (int d = 0; d < 15; ++d) mc.x_out[(size_t)d * mc.ld + g_local] = x[d];
+    }
+    SampleIn<true> v;
+    v.P_b = x[0]; v.x0 = x[1]; v.x1 = x[2]; v.x2 = x[3]; v.x3 = x[4]; v.x4 = x[5]; v.x5 = x[6]; v.x6 = x[7];
+    v.c0 = x[8]; v.c1 = x[9]; v.c2 = x[10]; v.c3 = x[11]; v.c4 = x[12]; v.c5 = x[13]; v.sigma = x[14];
     return v;
 }
 
@@ -446,8 +481,9 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
     wave_lds_sync();  // params are rewritten by the next tile
 }
 
-template <int L, bool COUPLED, int JMODE>
-__global__ __launch_bounds__(WAVE * WPB) void plume_r1_kernel(PlumeIO io, CoupledIO cio, long long ntiles) {
+template <int L, bool COUPLED, int JMODE, bool MC = false>
+__global__ __launch_bounds__(WAVE * WPB) void plume_r1_kernel(PlumeIO io, CoupledIO cio, long long ntiles, McDesign mc) {
+    static_assert(!MC || COUPLED, "the fused Monte-Carlo mode generates the coupled inputs");
     static_assert(L == 2 || L == 4 || L == 8, "lanes per sample");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* lds = reinterpret_cast<double*>(smem_raw);
@@ -473,19 +509,33 @@ __global__ __launch_bounds__(WAVE * WPB) void plume_r1_kernel(PlumeIO io, Couple
     const long long nfull = io.n / WAVE;
     const long long me = (long long)blockIdx.x * WPB + wave, nwaves = (long long)gridDim.x * WPB;
     long long t = me;
-    if (t < nfull) {
-        SampleIn<COUPLED> nxt = load_sample<COUPLED>(io, cio, t * WAVE + lane);
+    if constexpr (MC) {
         for (; t < nfull; t += nwaves) {
-            const SampleIn<COUPLED> in = nxt;
-            if (t + nwaves < nfull) nxt = load_sample<COUPLED>(io, cio, (t + nwaves) * WAVE + lane);
+            const SampleIn<COUPLED> in = generate_sample(mc, t * WAVE + lane);
             process_tile<L, COUPLED, JMODE, true>(io, cio, m, in, t, lane, rad, inv_r2, inv_2pi_r2);
         }
-    }
-    // the ragged last tile (n % 64 samples) goes to the wave that would have been next in line for it
-    if (nfull < ntiles && (nfull % nwaves) == me) {
-        const long long g = nfull * WAVE + lane;
-        const SampleIn<COUPLED> in = load_sample<COUPLED>(io, cio, g < io.n ? g : io.n - 1);
-        process_tile<L, COUPLED, JMODE, false>(io, cio, m, in, nfull, lane, rad, inv_r2, inv_2pi_r2);
+        if (nfull < ntiles && (nfull % nwaves) == me) {
+            const long long g = nfull * WAVE + lane;
+            McDesign quiet = mc;
+            if (g >= io.n) quiet.x_out = nullptr;       // dead lanes recompute the last sample and store nothing
+            const SampleIn<COUPLED> in = generate_sample(quiet, g < io.n ? g : io.n - 1);
+            process_tile<L, COUPLED, JMODE, false>(io, cio, m, in, nfull, lane, rad, inv_r2, inv_2pi_r2);
+        }
+    } else {
+        if (t < nfull) {
+            SampleIn<COUPLED> nxt = load_sample<COUPLED>(io, cio, t * WAVE + lane);
+            for (; t < nfull; t += nwaves) {
+                const SampleIn<COUPLED> in = nxt;
+                if (t + nwaves < nfull) nxt = load_sample<COUPLED>(io, cio, (t + nwaves) * WAVE + lane);
+                process_tile<L, COUPLED, JMODE, true>(io, cio, m, in, t, lane, rad, inv_r2, inv_2pi_r2);
+            }
+        }
+        // the ragged last tile (n % 64 samples) goes to the wave that would have been next in line for it
+        if (nfull < ntiles && (nfull % nwaves) == me) {
+            const long long g = nfull * WAVE + lane;
+            const SampleIn<COUPLED> in = load_sample<COUPLED>(io, cio, g < io.n ? g : io.n - 1);
+            process_tile<L, COUPLED, JMODE, false>(io, cio, m, in, nfull, lane, rad, inv_r2, inv_2pi_r2);
+        }
     }
 }
 
@@ -683,19 +733,19 @@ int fast_grid(size_t lds_bytes, long long ntiles, unsigned* grid) {
     return PEM_OK;
 }
 
-template <int L, bool COUPLED, int JMODE>
-int launch_r1(const PlumeIO& io, const CoupledIO& cio, hipStream_t st) {
+template <int L, bool COUPLED, int JMODE, bool MC = false>
+int launch_r1(const PlumeIO& io, const CoupledIO& cio, hipStream_t st, const McDesign& mc = McDesign{}) {
     const size_t lds = (size_t)fast_lds_doubles<L, JMODE>() * 8;
     const long long ntiles = (io.n + WAVE - 1) / WAVE;
     unsigned grid = 0;
     if (int rc = fast_grid(lds, ntiles, &grid)) return rc;
-    auto kern = plume_r1_kernel<L, COUPLED, JMODE>;
+    auto kern = plume_r1_kernel<L, COUPLED, JMODE, MC>;
     if (lds > 64 * 1024) {
         static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         HIP_TRY(attr);
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * WPB), lds, st, io, cio, ntiles);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * WPB), lds, st, io, cio, ntiles, mc);
     HIP_TRY(hipGetLastError());
     return PEM_OK;
 }
@@ -877,6 +927,36 @@ int pem_coupled_f64_dev(size_t n, double torr2pa, double radius, const double* P
     PlumeIO io{(long long)n, torr2pa, radius, P_b, c0, c1, c2, c3, c4, c5, sigma_cex, nullptr, nullptr, j_ion, div_angle, T_c, invalid};
     CoupledIO cio{V_a, T_e, V_vac, Pstar, P_T, mdot_a, a_1, V_cc, I_B0, T};
     return j_ion ? dispatch_lanes<true, 1>(io, cio, st) : dispatch_lanes<true, 0>(io, cio, st);
+}
+
+// ---- coupled, fused Monte-Carlo: inputs generated from the counter-based design inside the kernel ------------
+int pem_coupled_mc_f64_dev(size_t n, uint64_t first_index, uint64_t seed, uint32_t stream_id, const int32_t* kind,
+                           const double* a, const double* b, double torr2pa, double radius, double* x_out, size_t ld,
+                           double* V_cc, double* I_B0, double* T, double* j_ion, double* div_angle, double* T_c,
+                           uint8_t* invalid, pem_stream_t stream) {
+    if (n == 0) return PEM_OK;
+    if (!kind || !a || !b || !V_cc || !div_angle || !T_c) return fail(PEM_ERR_INVALID_ARG, "pem_coupled_mc: NULL array");
+    if (j_ion && !aligned16(j_ion)) return fail(PEM_ERR_INVALID_ARG, "pem_coupled_mc: j_ion must be 16-byte aligned");
+    if (x_out && ld < n) return fail(PEM_ERR_INVALID_ARG, "pem_coupled_mc: leading dimension smaller than n");
+    if (int rc = check_device()) return rc;
+    McDesign mc{};
+    mc.seed = seed;
+    mc.first = first_index;
+    mc.stream = stream_id;
+    mc.enabled = 1;
+    for (int d = 0; d < 15; ++d) {
+        if (kind[d] < PEM_DIST_UNIFORM || kind[d] > PEM_DIST_NORMAL)
+            return fail(PEM_ERR_INVALID_ARG, "pem_coupled_mc: unknown distribution kind %d for input %d", kind[d], d);
+        mc.kind[d] = kind[d];
+        mc.a[d] = a[d];
+        mc.b[d] = b[d];
+    }
+    mc.x_out = x_out;
+    mc.ld = ld;
+    PlumeIO io{(long long)n, torr2pa, radius, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, j_ion, div_angle, T_c, invalid, nullptr};
+    CoupledIO cio{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, V_cc, I_B0, T};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return j_ion ? launch_r1<4, true, 1, true>(io, cio, st, mc) : launch_r1<4, true, 0, true>(io, cio, st, mc);
 }
 
 // ---- coupled, mixed precision: fp64 arithmetic, the 91-point profile stored as fp32 -----------------

@@ -90,8 +90,11 @@ def forward_uq(n: int, seed: int = 0, method: str = 'mc', profile: bool = False,
         m = min(bs, n_local - off)
         if m < bs:                      # the ragged last batch: a right-sized batch keeps the kernel launch exact
             batch = CoupledBatch(m, device=dev, profile=profile or keep_profile)
-        design.fill(batch.inputs, first_index=lo + off, method=method, n_total=n)
-        batch.run()
+        if method == 'mc':      # fused: the inputs are generated inside the evaluation kernel (and stored for `x`)
+            batch.run_mc(design, first_index=lo + off, write_inputs=True)
+        else:
+            design.fill(batch.inputs, first_index=lo + off, method=method, n_total=n)
+            batch.run()
         res = batch.outputs()
         sl = slice(off, off + m)
         for k in QOI_NAMES + ('I_B0', 'T', 'invalid'):
