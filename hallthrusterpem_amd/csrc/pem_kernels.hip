@@ -222,6 +222,12 @@ __device__ __forceinline__ SampleIn<COUPLED> load_sample(const PlumeIO& io, cons
     return v;
 }
 
+// Out of line on purpose: inlined fifteen times, the library exp / normcdfinv bodies of the transforms pushed the
+// fused kernel past 256 VGPRs (204 bytes of scratch per lane).
+__device__ __attribute__((noinline)) double transform_call(int kind, double a, double b, double u) {
+    return pem::transform(kind, a, b, u);
+}
+
 // inputs of global sample `g` from the design: bit-identical to pem_sample_f64_dev followed by a load
 __device__ __forceinline__ SampleIn<true> generate_sample(const McDesign& mc, long long g_local) {
     const unsigned long long g = mc.first + (unsigned long long)g_local;
@@ -230,9 +236,9 @@ __device__ __forceinline__ SampleIn<true> generate_sample(const McDesign& mc, lo
 #pragma unroll
     for (int pair = 0; pair < 8; ++pair) {
         const pem::Philox4 r = pem::philox4x32_10((unsigned int)g, (unsigned int)(g >> 32), (unsigned int)pair, mc.stream, k0, k1);
-        x[2 * pair] = pem::transform(mc.kind[2 * pair], mc.a[2 * pair], mc.b[2 * pair], pem::u53(r.x, r.y));
+        x[2 * pair] = transform_call(mc.kind[2 * pair], mc.a[2 * pair], mc.b[2 * pair], pem::u53(r.x, r.y));
         if (2 * pair + 1 < 15)
-            x[2 * pair + 1] = pem::transform(mc.kind[2 * pair + 1], mc.a[2 * pair + 1], mc.b[2 * pair + 1], pem::u53(r.z, r.w));
+            x[2 * pair + 1] = transform_call(mc.kind[2 * pair + 1], mc.a[2 * pair + 1], mc.b[2 * pair + 1], pem::u53(r.z, r.w));
     }
     if (mc.x_out) {
 #pragma unroll
