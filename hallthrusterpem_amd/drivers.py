@@ -180,3 +180,36 @@ def sobol_indices(n_base: int, seed: int = 0, qois=QOI_NAMES, priors=None, fixed
     return {'S1': {q: S1[:, i] for i, q in enumerate(qois)}, 'ST': {q: ST[:, i] for i, q in enumerate(qois)},
             'inputs': names, 'mean': {q: mean[i] for i, q in enumerate(qois)}, 'var': {q: var[i] for i, q in enumerate(qois)},
             'evaluations': int(n_base) * (nd + 2)}
+
+
+# ------------------------------------------------------------------------------------------- rejection of plume spikes
+PLUME_INPUTS = ('P_b', 'c0', 'c1', 'c2', 'c3', 'c4', 'c5', 'sigma_cex')
+
+
+def sample_plume_without_spikes(n: int, seed: int = 0, threshold: float = 200.0, I_B0: float = 4.0, radius: float = 1.0,
+                                priors=None, max_rounds: int = 64, device=None):
+    """Plume inputs whose profile stays below `threshold` A/m^2 everywhere: the rejection loop of the reference's Sobol'
+    sampler (scripts/pem_v0/sobol.py:50-66: evaluate the plume at r = 1 m, I_B0 = 4 A, redraw every sample with any
+    j >= 200 until none is left).
+
+    Deterministic: attempt k of global sample i is draw i of stream 2k of the counter-based design, so the accepted
+    set does not depend on batching.  Returns ([8][n] CUDA tensor in PLUME_INPUTS order, number of rounds)."""
+    import torch
+    from .models.plume import current_density
+    pri = sampling.PEM_V0_PRIORS if priors is None else priors
+    dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    x = sampling.Design(priors=pri, names=PLUME_INPUTS, seed=seed, stream=0).sample(n, device=dev)
+    pending = torch.arange(n, device=dev)
+    ib0 = torch.full((1,), float(I_B0), dtype=torch.float64, device=dev)
+    for attempt in range(max_rounds):
+        cur = x[:, pending]
+        ins = {k: cur[i] for i, k in enumerate(PLUME_INPUTS)}
+        ins['I_B0'] = ib0.expand(pending.numel())
+        j = current_density(ins, sweep_radius=radius)['j_ion']
+        bad = (j >= threshold).any(dim=-1)
+        if not bool(bad.any()):
+            return x, attempt + 1
+        pending = pending[bad]
+        redraw = sampling.Design(priors=pri, names=PLUME_INPUTS, seed=seed, stream=2 * (attempt + 1)).sample(n, device=dev)
+        x[:, pending] = redraw[:, pending]
+    raise RuntimeError(f'{pending.numel()} samples still exceed {threshold} A/m^2 after {max_rounds} rounds')

@@ -134,3 +134,23 @@ def test_fused_monte_carlo_equals_sample_then_evaluate():
         quiet.run_mc(design, first_index=first)                 # reduced QoIs, inputs never written
         torch.cuda.synchronize()
         assert torch.equal(quiet.qoi, ref.qoi) and bool((quiet.inputs == -1.0).all())
+
+
+@pytest.mark.gpu
+def test_rejection_of_plume_spikes():
+    from hallthrusterpem_amd.models.plume import current_density
+    n = 50_000
+    thr = 20.0      # the PEM-v0 priors rarely reach the reference's 200 A/m^2; a lower bar exercises the redraw loop
+    x, rounds = drivers.sample_plume_without_spikes(n, seed=13, threshold=thr)
+    assert x.shape == (8, n) and rounds >= 2
+    ins = {k: x[i] for i, k in enumerate(drivers.PLUME_INPUTS)}
+    ins['I_B0'] = torch.full((n,), 4.0, dtype=torch.float64, device='cuda')
+    j = current_density(ins)['j_ion']
+    assert float(j.max()) < thr
+    raw = drivers.sampling.Design(names=drivers.PLUME_INPUTS, seed=13).sample(n)
+    kept = (x == raw).all(dim=0)
+    assert 0.5 < float(kept.float().mean()) < 1.0                    # accepted first draws are untouched
+    again, _ = drivers.sample_plume_without_spikes(n, seed=13, threshold=thr)
+    same, one = drivers.sample_plume_without_spikes(n, seed=13, threshold=1e9)
+    assert one == 1 and torch.equal(same, raw)
+    assert torch.equal(again, x)                                     # deterministic
