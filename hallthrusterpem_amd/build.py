@@ -6,9 +6,9 @@ from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
-SRCS = [PKG / 'csrc' / 'pem_kernels.hip', PKG / 'csrc' / 'pem_sampler.hip', PKG / 'csrc' / 'pem_svd.hip', PKG / 'csrc' / 'pem_likelihood.hip']
+SRCS = [PKG / 'csrc' / 'pem_kernels.hip', PKG / 'csrc' / 'pem_sampler.hip', PKG / 'csrc' / 'pem_svd.hip', PKG / 'csrc' / 'pem_likelihood.hip', PKG / 'csrc' / 'pem_surrogate.hip']
 LIB = PKG / 'libpem_hip.so'
-DEPS = SRCS + [PKG / 'csrc' / 'pem_tables.h', PKG / 'csrc' / 'pem_common.h', ROOT / 'include' / 'pem_hip.h']
+DEPS = SRCS + [PKG / 'csrc' / 'pem_tables.h', PKG / 'csrc' / 'pem_common.h', PKG / 'csrc' / 'pem_philox.h', ROOT / 'include' / 'pem_hip.h']
 
 
 def hipcc() -> str:
