@@ -132,8 +132,14 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
     local_dev = local_rank % max(1, torch.cuda.device_count())   # == local_rank on a real multi-GPU node
     torch.cuda.set_device(local_dev)
-    if world > 1:
+    # PEM_BENCH_FORCE_DIST=1: take the N > 1 code path (process group, overlapped all-gather) with a single rank,
+    # to rehearse the RCCL calls on a one-GPU box
+    multi = world > 1 or os.environ.get('PEM_BENCH_FORCE_DIST') == '1'
+    if multi:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         if args.dist_backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_dev))
         else:
@@ -148,7 +154,7 @@ def main():
     synth_inputs(batch, args.seed, rank)
     # N > 1: the all-gather of step i runs beside the evaluation of step i+1 (RCCL works on its own stream):
     # two batches alternate so a QoI buffer is not rewritten while it is still being sent.
-    nbuf = 2 if (world > 1 and args.gather != 'none') else 1
+    nbuf = 2 if (multi and args.gather != 'none') else 1
     batches = [batch]
     for _ in range(nbuf - 1):
         b2 = CoupledBatch(n, profile=not args.no_profile, mixed=args.mixed, thruster_qoi=False)
@@ -156,9 +162,9 @@ def main():
         batches.append(b2)
     gathered, pending = [], [None] * nbuf
     for b in batches:
-        if world > 1 and args.gather == 'qoi':
+        if multi and args.gather == 'qoi':
             gathered.append(torch.empty((world * b.qoi.shape[0], n), dtype=torch.float64, device=b.device))
-        elif world > 1 and args.gather == 'full':
+        elif multi and args.gather == 'full':
             gathered.append(torch.empty((world * n, b.j_ion.shape[1]), dtype=b.j_ion.dtype, device=b.device))
     counter = [0]
 
@@ -182,7 +188,7 @@ def main():
     def fence():
         drain()
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -193,7 +199,7 @@ def main():
             step()
         fence()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if multi:
             t = torch.tensor([dt], dtype=torch.float64, device=batch.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -232,7 +238,7 @@ def main():
                                    'BASELINE configs[2] shard (1e7 samples / 8 GPUs), 91 angles, R=1 at 1.0 m',
                        'samples_per_gpu': n, 'global_samples_per_step': world * n, 'seed': args.seed,
                        'TORR_2_PA': 133.322, 'lanes_per_sample': lanes, 'profile_written': not args.no_profile,
-                       'gather': (args.gather + ', overlapped with the next step') if (world > 1 and args.gather != 'none') else 'none',
+                       'gather': (args.gather + ', overlapped with the next step') if (multi and args.gather != 'none') else 'none',
                        'value_without_gather': (world * n * args.steps / elapsed_nogather) if elapsed_nogather else None,
                        'parallelism': f'sample-shard x{world}',
                        'invalid_fraction': frac_invalid},
@@ -247,7 +253,7 @@ def main():
         else:
             line['cpu_baseline'] = None
         print(json.dumps(line))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

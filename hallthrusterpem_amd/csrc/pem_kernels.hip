@@ -164,7 +164,6 @@ struct CoupledIO {
 struct McDesign {
     unsigned long long seed, first;
     unsigned int stream;
-    int enabled;
     int kind[15];
     double a[15], b[15];
     double* x_out;          // optional [15][ld] copy of the generated inputs
@@ -949,7 +948,6 @@ int pem_coupled_mc_f64_dev(size_t n, uint64_t first_index, uint64_t seed, uint32
     mc.seed = seed;
     mc.first = first_index;
     mc.stream = stream_id;
-    mc.enabled = 1;
     for (int d = 0; d < 15; ++d) {
         if (kind[d] < PEM_DIST_UNIFORM || kind[d] > PEM_DIST_NORMAL)
             return fail(PEM_ERR_INVALID_ARG, "pem_coupled_mc: unknown distribution kind %d for input %d", kind[d], d);
