@@ -62,7 +62,7 @@ class CoupledBatch:
         rc = fn(self.n, constants.TORR_2_PA, self.radius, *self._in_ptrs, *self._out_ptrs, C.c_void_p(s.cuda_stream))
         _lib.check(rc)
 
-    def run_mc(self, design, first_index: int = 0, write_inputs: bool = False, stream=None):
+    def run_mc(self, design, first_index: int = 0, write_inputs: bool = False, swap_dim: int = -1, stream=None):
         """Fused Monte-Carlo step: generate samples first_index .. first_index+n-1 of `design` (a sampling.Design over
         the 15 coupled inputs) inside the kernel and evaluate them; `write_inputs` also stores them in `self.inputs`."""
         import torch
@@ -71,7 +71,7 @@ class CoupledBatch:
             raise NotImplementedError('fused Monte-Carlo mode writes an fp64 profile or none')
         ptr = lambda arr: C.c_void_p(arr.ctypes.data)                                           # noqa: E731
         rc = _lib.load().pem_coupled_mc_f64_dev(
-            self.n, int(first_index), design.seed, design.stream, ptr(design.kind), ptr(design.a), ptr(design.b),
+            self.n, int(first_index), design.seed, design.stream, int(swap_dim), ptr(design.kind), ptr(design.a), ptr(design.b),
             constants.TORR_2_PA, self.radius, C.c_void_p(self.inputs.data_ptr()) if write_inputs else None,
             self.inputs.stride(0), *self._out_ptrs, C.c_void_p(s.cuda_stream))
         _lib.check(rc)

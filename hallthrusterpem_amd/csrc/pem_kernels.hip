@@ -164,6 +164,7 @@ struct CoupledIO {
 struct McDesign {
     unsigned long long seed, first;
     unsigned int stream;
+    int swap_dim;           // Saltelli blocks, as pem_sample_f64_dev: -1 plain, -2 all from stream+1, d >= 0 column d
     int kind[15];
     double a[15], b[15];
     double* x_out;          // optional [15][ld] copy of the generated inputs
@@ -234,10 +235,16 @@ __device__ __forceinline__ SampleIn<true> generate_sample(const McDesign& mc, lo
     double x[16];
 #pragma unroll
     for (int pair = 0; pair < 8; ++pair) {
-        const pem::Philox4 r = pem::philox4x32_10((unsigned int)g, (unsigned int)(g >> 32), (unsigned int)pair, mc.stream, k0, k1);
+        // the two dimensions of a pair may come from different streams in a Saltelli block (wave-uniform choice)
+        const unsigned int st0 = mc.stream + ((mc.swap_dim == -2 || mc.swap_dim == 2 * pair) ? 1u : 0u);
+        const unsigned int st1 = mc.stream + ((mc.swap_dim == -2 || mc.swap_dim == 2 * pair + 1) ? 1u : 0u);
+        const pem::Philox4 r = pem::philox4x32_10((unsigned int)g, (unsigned int)(g >> 32), (unsigned int)pair, st0, k0, k1);
         x[2 * pair] = transform_call(mc.kind[2 * pair], mc.a[2 * pair], mc.b[2 * pair], pem::u53(r.x, r.y));
-        if (2 * pair + 1 < 15)
-            x[2 * pair + 1] = transform_call(mc.kind[2 * pair + 1], mc.a[2 * pair + 1], mc.b[2 * pair + 1], pem::u53(r.z, r.w));
+        if (2 * pair + 1 < 15) {
+            pem::Philox4 r1 = r;
+            if (st1 != st0) r1 = pem::philox4x32_10((unsigned int)g, (unsigned int)(g >> 32), (unsigned int)pair, st1, k0, k1);
+            x[2 * pair + 1] = transform_call(mc.kind[2 * pair + 1], mc.a[2 * pair + 1], mc.b[2 * pair + 1], pem::u53(r1.z, r1.w));
+        }
     }
     if (mc.x_out) {
 #pragma unroll
@@ -935,19 +942,22 @@ int pem_coupled_f64_dev(size_t n, double torr2pa, double radius, const double* P
 }
 
 // ---- coupled, fused Monte-Carlo: inputs generated from the counter-based design inside the kernel ------------
-int pem_coupled_mc_f64_dev(size_t n, uint64_t first_index, uint64_t seed, uint32_t stream_id, const int32_t* kind,
-                           const double* a, const double* b, double torr2pa, double radius, double* x_out, size_t ld,
+int pem_coupled_mc_f64_dev(size_t n, uint64_t first_index, uint64_t seed, uint32_t stream_id, int swap_dim,
+                           const int32_t* kind, const double* a, const double* b, double torr2pa, double radius,
+                           double* x_out, size_t ld,
                            double* V_cc, double* I_B0, double* T, double* j_ion, double* div_angle, double* T_c,
                            uint8_t* invalid, pem_stream_t stream) {
     if (n == 0) return PEM_OK;
     if (!kind || !a || !b || !V_cc || !div_angle || !T_c) return fail(PEM_ERR_INVALID_ARG, "pem_coupled_mc: NULL array");
     if (j_ion && !aligned16(j_ion)) return fail(PEM_ERR_INVALID_ARG, "pem_coupled_mc: j_ion must be 16-byte aligned");
     if (x_out && ld < n) return fail(PEM_ERR_INVALID_ARG, "pem_coupled_mc: leading dimension smaller than n");
+    if (swap_dim < -2 || swap_dim >= 15) return fail(PEM_ERR_INVALID_ARG, "pem_coupled_mc: swap_dim out of range");
     if (int rc = check_device()) return rc;
     McDesign mc{};
     mc.seed = seed;
     mc.first = first_index;
     mc.stream = stream_id;
+    mc.swap_dim = swap_dim;
     for (int d = 0; d < 15; ++d) {
         if (kind[d] < PEM_DIST_UNIFORM || kind[d] > PEM_DIST_NORMAL)
             return fail(PEM_ERR_INVALID_ARG, "pem_coupled_mc: unknown distribution kind %d for input %d", kind[d], d);

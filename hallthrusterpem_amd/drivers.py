@@ -149,11 +149,13 @@ def sobol_indices(n_base: int, seed: int = 0, qois=QOI_NAMES, priors=None, fixed
     dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
     acc = torch.zeros((3 + 2 * nd, nq), dtype=torch.float64, device=dev)   # sum f, sum f^2, count | S1 sums | ST sums
 
+    rows = [{'V_cc': 0, 'div_angle': 1, 'T_c': 2}.get(k) for k in qois]
+    if any(r is None for r in rows):
+        raise ValueError(f'sobol_indices handles the scalar QoIs V_cc, div_angle, T_c; got {qois}')
+
     def run(batch, first, swap):
-        design.fill(batch.inputs, first_index=first, swap_dim=swap)
-        batch.run()
-        o = batch.outputs()
-        return torch.stack([o[k] for k in qois], dim=1).clone()        # [m][nq]
+        batch.run_mc(design, first_index=first, swap_dim=swap)         # Saltelli block generated inside the kernel
+        return batch.qoi[rows].T.clone()                               # [m][nq]
 
     batch = None
     for off in range(lo, hi, bs):

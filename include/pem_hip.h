@@ -201,9 +201,10 @@ int pem_sparse_predict_f64_dev(size_t n, int n_dim, int n_beta, const int32_t* i
  * first_index .. first_index+n-1 are generated in registers from the counter-based design (kind/a/b as for
  * pem_sample_f64_dev, input order P_b V_a T_e V_vac Pstar P_T mdot_a a_1 c0..c5 sigma_cex) and never touch HBM
  * unless x_out ([15][ld], ld >= n) is given.  Results are bit-identical to pem_sample_f64_dev followed by
- * pem_coupled_f64_dev.  752 instead of 872 bytes per evaluation.                                         */
-int pem_coupled_mc_f64_dev(size_t n, uint64_t first_index, uint64_t seed, uint32_t stream_id, const int32_t* kind,
-                           const double* a, const double* b, double torr2pa, double radius, double* x_out, size_t ld,
+ * pem_coupled_f64_dev (swap_dim selects the Saltelli block as there).  752 instead of 872 bytes per evaluation. */
+int pem_coupled_mc_f64_dev(size_t n, uint64_t first_index, uint64_t seed, uint32_t stream_id, int swap_dim,
+                           const int32_t* kind, const double* a, const double* b, double torr2pa, double radius,
+                           double* x_out, size_t ld,
                            double* V_cc, double* I_B0, double* T, double* j_ion, double* div_angle, double* T_c,
                            uint8_t* invalid, pem_stream_t stream);
 
