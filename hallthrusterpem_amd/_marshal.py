@@ -59,3 +59,22 @@ def pick_device(values):
         if is_torch(v) and v.is_cuda:
             return v.device
     raise ValueError('no CUDA tensor among the inputs')
+
+
+PINNED_THRESHOLD_BYTES = 32 << 20
+
+
+def host_empty(n: int, dtype=np.float64) -> np.ndarray:
+    """Uninitialised flat host array for results.  Large results are taken from torch's caching pinned-memory
+    allocator: a device-to-host copy into page-locked memory runs at PCIe rate (~50 GB/s) instead of the ~18 GB/s of
+    pageable memory, and the allocator reuses the pinned block once the array is garbage-collected, so a sampling
+    loop pays the pinning once.  Falls back to np.empty if pinned memory is not available."""
+    nbytes = int(n) * np.dtype(dtype).itemsize
+    if nbytes >= PINNED_THRESHOLD_BYTES:
+        try:
+            import torch
+            tdtype = {np.dtype(np.float64): torch.float64, np.dtype(np.uint8): torch.uint8}[np.dtype(dtype)]
+            return torch.empty(int(n), dtype=tdtype, pin_memory=True).numpy()
+        except Exception:
+            pass
+    return np.empty(int(n), dtype=dtype)

@@ -60,7 +60,7 @@ def pem_v0_coupled(inputs: dict, sweep_radius: float = 1.0, profile: bool = True
     else:
         flat = [m.host_flat(v, shape) for v in vals]
         o = {k: np.empty(n, dtype=np.float64) for k in names}
-        j = np.empty(n * _lib.NANGLE, dtype=np.float64) if profile else None
+        j = m.host_empty(n * _lib.NANGLE) if profile else None
         inv = np.zeros(n, dtype=np.uint8)
         _lib.check(lib.pem_coupled_f64(n, constants.TORR_2_PA, radius, *[m.np_ptr(a) for a in flat],
                                        m.np_ptr(o['V_cc']), m.np_ptr(o['I_B0']), m.np_ptr(o['T']), m.np_ptr(j),

@@ -69,7 +69,7 @@ def current_density(inputs: dict, sweep_radius=1.0) -> dict:
 
     flat = [m.host_flat(v, shape) for v in vals]
     t_in = m.host_flat(thrust, shape) if thrust is not None else None
-    j = np.empty(n * _lib.NANGLE * R, dtype=np.float64)
+    j = m.host_empty(n * _lib.NANGLE * R)
     div = np.empty(n * R, dtype=np.float64)
     tc = np.empty(n * R, dtype=np.float64) if thrust is not None else None
     _lib.check(lib.pem_plume_f64(n, R, m.np_ptr(radii), constants.TORR_2_PA, *[m.np_ptr(a) for a in flat],
