@@ -120,6 +120,12 @@ def main():
     ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL; default) or gloo (rehearsal on one GPU)')
     args = ap.parse_args()
 
+    # stdout carries exactly one JSON line: everything libraries print meanwhile (RCCL writes its version banner to
+    # stdout under NCCL_DEBUG=VERSION) is sent to stderr by pointing fd 1 at fd 2 until the line is ready
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from hallthrusterpem_amd import _lib
@@ -252,7 +258,10 @@ def main():
             line['cpu_baseline'] = cpu_baseline()
         else:
             line['cpu_baseline'] = None
-        print(json.dumps(line))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
     if multi:
         dist.destroy_process_group()
 
