@@ -156,8 +156,9 @@ def test_thruster_stage_vs_oracle(pem, oc):
         assert rel_err(got[k], want[k]) <= 1e-15, k        # same IEEE operations, no transcendental but sqrt
 
 
-@pytest.mark.parametrize('n', [1, 64, 100_000])
+@pytest.mark.parametrize('n', [1, 64, 100_000, 1_250_000])      # the last one is BASELINE configs[2]'s per-GPU shard
 def test_coupled_vs_oracle(pem, oc, n):
+    oc.set_threads(16)
     from hallthrusterpem_amd.models import pem_v0_coupled
     x = coupled_inputs(n, seed=2)
     got = pem_v0_coupled(x)
@@ -206,10 +207,10 @@ def test_device_tensors_match_host_path(pem):
 
 # ---------------------------------------------------------------------------------------------- full-size properties
 def test_config2_full_size_properties(pem, oc):
-    """BASELINE.json configs[1]: 1e6 MC samples of the plume model, R = 1, fp64 -- too many for the oracle in
-    seconds, so: (a) a strided 1-in-500 subsample against the oracle, (b) shard invariance (samples are
-    independent: evaluating two halves equals evaluating the whole, bit for bit), (c) determinism,
-    (d) the reference's own invariant, total current = I_B0 (tests/test_plume.py:91-98), (e) range."""
+    """BASELINE.json configs[1]: 1e6 MC samples of the plume model, R = 1, fp64.  (a) ALL 1e6 samples against the
+    oracle (OpenMP, a fraction of a second on the box's CPU share), (b) shard invariance (samples are independent:
+    evaluating two halves equals evaluating the whole, bit for bit), (c) determinism, (d) the reference's own
+    invariant, total current = I_B0 (tests/test_plume.py:91-98), (e) range, (f) linearity in I_B0."""
     import torch
     from hallthrusterpem_amd.models import current_density
     n = 1_000_000
@@ -217,10 +218,17 @@ def test_config2_full_size_properties(pem, oc):
     xd = {k: torch.from_numpy(v).cuda() for k, v in x.items()}
     out = current_density(xd)
     j = out['j_ion']
-    sub = slice(0, n, 500)
-    ref = oc.plume(*[x[k][sub] for k in PLUME_KEYS], pem.constants.TORR_2_PA, T=x['T'][sub])
-    assert rel_err(j[sub].cpu().numpy(), ref['j_ion'][:, :, 0]) <= RTOL
-    assert div_err(out['div_angle'][sub].cpu().numpy(), ref['div_angle'][:, 0]) <= RTOL
+    oc.set_threads(16)
+    ref = oc.plume(*[x[k] for k in PLUME_KEYS], pem.constants.TORR_2_PA, T=x['T'])
+    assert rel_err(j.cpu().numpy(), ref['j_ion'][:, :, 0]) <= RTOL
+    assert div_err(out['div_angle'].cpu().numpy(), ref['div_angle'][:, 0]) <= RTOL
+    assert rel_err(out['T_c'].cpu().numpy(), ref['T_c'][:, 0]) <= RTOL
+    del ref
+    # j_ion is linear in the beam current: scaling I_B0 by a power of two scales every output entry exactly
+    x4 = dict(xd)
+    x4['I_B0'] = xd['I_B0'] * 4.0
+    j4 = current_density(x4)
+    assert torch.equal(j4['j_ion'], 4.0 * j) and torch.equal(j4['div_angle'], out['div_angle'])
     half = n // 2 + 17
     lo = current_density({k: v[:half] for k, v in xd.items()})
     hi = current_density({k: v[half:] for k, v in xd.items()})

@@ -22,6 +22,7 @@ def main():
     ap.add_argument('--rounds', type=int, default=15)
     ap.add_argument('--reps', type=int, default=8)
     ap.add_argument('--no-profile', action='store_true')
+    ap.add_argument('--no-invalid', action='store_true', help='pass NULL for the invalid-flag array')
     ap.add_argument('variants', nargs='+')
     args = ap.parse_args()
 
@@ -31,7 +32,9 @@ def main():
     import bench
     _lib.load()                     # maps torch's HIP runtime first; every variant then shares it
     _lib.require_device()
-    batch = CoupledBatch(args.n, profile=not args.no_profile)
+    batch = CoupledBatch(args.n, profile=not args.no_profile, thruster_qoi=False)
+    if args.no_invalid:
+        batch._out_ptrs[-1] = None
     bench.synth_inputs(batch, 2, 0)
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
