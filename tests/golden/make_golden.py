@@ -104,6 +104,18 @@ def main():
     _save('cathode_edges', **{f'in_{k}': v for k, v in ce.items()}, out_V_cc=vcc_e,
           scalar_out_V_cc=vcc_s, sweep_in_P_b=sweep_pb, sweep_out_V_cc=vcc_sw)
 
+    # wild cathode inputs: zero / negative pressures (log of a non-positive number), huge ratios, negative voltages
+    rng = np.random.default_rng(20260108)
+    N = 400
+    pick = lambda vals, size: rng.choice(np.asarray(vals, dtype=np.float64), size=size)                 # noqa: E731
+    cw = {'P_b': 10 ** rng.uniform(-10, -1, N) * pick([1, 1, 1, 0, -1], N), 'V_a': rng.uniform(-50, 500, N),
+          'T_e': rng.uniform(-1, 8, N), 'V_vac': rng.uniform(-20, 100, N),
+          'Pstar': 10 ** rng.uniform(-8, -3, N) * pick([1, 1, 1, 0, -1], N),
+          'P_T': 10 ** rng.uniform(-8, -3, N) * pick([1, 1, 1, 0, -1], N)}
+    with np.errstate(all='ignore'):
+        vw = cathode.cathode_coupling(dict(cw))['V_cc']
+    _save('cathode_wild', **{f'in_{k}': v for k, v in cw.items()}, out_V_cc=vw)
+
     # ---- plume: tests/test_plume.py:19-31 ranges (reaches the invalid alpha1<=0 branch), 5 radii ----
     rng = np.random.default_rng(20260102)
     N = 96
@@ -160,6 +172,18 @@ def main():
           **_plume_out(plume, pin, 1.0))
     rr = np.array([0.5, 1.0, 2.5])
     _save('plume_edges_r3', **{f'in_{k}': v for k, v in pin.items()}, radii=rr, **_plume_out(plume, pin, rr))
+
+    # wild inputs far outside the priors (signs, zeros, huge/tiny magnitudes): NaN / inf / invalid patterns must agree
+    rng = np.random.default_rng(20260107)
+    N = 600
+    pick = lambda vals, size: rng.choice(np.asarray(vals, dtype=np.float64), size=size)                 # noqa: E731
+    pin = {'P_b': 10 ** rng.uniform(-10, -2, N) * pick([1, 1, 1, 0], N),
+           'c0': rng.uniform(-0.5, 1.5, N), 'c1': rng.uniform(-1.0, 1.2, N) * pick([1, 1, 1, 1, 0.01], N),
+           'c2': rng.uniform(-40, 40, N), 'c3': rng.uniform(-0.5, 2.5, N) * pick([1, 1, 1, 0], N),
+           'c4': 10 ** rng.uniform(15, 24, N) * pick([1, 1, 0], N), 'c5': 10 ** rng.uniform(10, 20, N) * pick([1, 1, 0], N),
+           'sigma_cex': rng.uniform(0, 1e-18, N), 'I_B0': rng.uniform(-2, 10, N) * pick([1, 1, 1, 0], N),
+           'T': rng.uniform(-0.05, 0.2, N)}
+    _save('plume_wild', **{f'in_{k}': v for k, v in pin.items()}, radii=np.array([1.0]), **_plume_out(plume, pin, 1.0))
 
     # shape semantics: all-scalar inputs (leading axis of 1), loop shape (3, 4) with R = 2, no thrust
     sc = {k: v for k, v in base.items() if k != 'T'}

@@ -51,9 +51,11 @@ def test_cathode_golden(pem):
     out = cathode_coupling({k: g['in_' + k] for k in ('P_b', 'V_a', 'T_e', 'V_vac', 'Pstar', 'P_T')})
     assert rel_err(out['V_cc'], g['out_V_cc']) <= RTOL
     assert np.all(out['V_cc'] >= 0) and np.all(out['V_cc'] <= 100)                  # tests/test_cathode.py:24
+    for name in ('cathode_edges', 'cathode_wild'):
+        g = load_golden(name)
+        out = cathode_coupling({k: g['in_' + k] for k in ('P_b', 'V_a', 'T_e', 'V_vac', 'Pstar', 'P_T')})
+        assert rel_err(out['V_cc'], g['out_V_cc']) <= RTOL
     g = load_golden('cathode_edges')
-    out = cathode_coupling({k: g['in_' + k] for k in ('P_b', 'V_a', 'T_e', 'V_vac', 'Pstar', 'P_T')})
-    assert rel_err(out['V_cc'], g['out_V_cc']) <= RTOL
     s = cathode_coupling({'P_b': 10e-6, 'V_a': 300, 'T_e': 3, 'V_vac': 30, 'Pstar': 20e-6, 'P_T': 50e-6})
     assert s['V_cc'].shape == (1,) and rel_err(s['V_cc'], g['scalar_out_V_cc']) <= RTOL   # test_cathode.py:14-15
     sw = cathode_coupling({'P_b': g['sweep_in_P_b'], 'V_a': 300, 'T_e': 1.33, 'V_vac': 31.6, 'Pstar': 24.6e-6,
@@ -64,7 +66,7 @@ def test_cathode_golden(pem):
 
 
 @pytest.mark.parametrize('name', ['plume_random_r1', 'plume_priors_r1', 'plume_alpha_sweep', 'plume_random_r5',
-                                  'plume_edges', 'plume_edges_r3', 'plume_pressure_sweep'])
+                                  'plume_edges', 'plume_edges_r3', 'plume_wild', 'plume_pressure_sweep'])
 def test_plume_golden(pem, name):
     from hallthrusterpem_amd.models import current_density
     g = load_golden(name)

@@ -31,6 +31,13 @@ def test_cathode_random():
     assert np.all(got >= 0) and np.all(got <= 100)          # tests/test_cathode.py:24
 
 
+def test_cathode_wild_inputs():
+    g = load_golden('cathode_wild')
+    got = oc.cathode(g['in_P_b'], g['in_V_a'], g['in_T_e'], g['in_V_vac'], g['in_Pstar'], g['in_P_T'], float(g['TORR_2_PA']))
+    assert rel_err(got, g['out_V_cc']) <= 1e-15          # NaN / inf patterns identical, values to an ulp of log()
+    assert np.isnan(g['out_V_cc']).sum() > 20
+
+
 def test_cathode_edges_scalar_sweep():
     g = load_golden('cathode_edges')
     k = float(g['TORR_2_PA'])
@@ -46,7 +53,7 @@ def test_cathode_edges_scalar_sweep():
 
 
 @pytest.mark.parametrize('name', ['plume_random_r1', 'plume_priors_r1', 'plume_alpha_sweep', 'plume_random_r5',
-                                  'plume_edges', 'plume_edges_r3'])
+                                  'plume_edges', 'plume_edges_r3', 'plume_wild'])
 def test_plume_against_reference(name):
     g = load_golden(name)
     T = g.get('in_T')
