@@ -122,3 +122,74 @@ int pem_sample_lhs_f64_dev(size_t n, uint64_t first_index, uint64_t n_total, uin
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// Saltelli accumulation: the per-batch sums behind the Sobol' estimators of hallthrusterpem_amd/drivers.py, one pass.
+//   fAB == NULL : out[b][q][0] += sum f_A + f_B,   out[b][q][1] += sum f_A^2 + f_B^2          (mean / variance)
+//   fAB != NULL : out[b][q][0] += sum f_B (f_AB - f_A),  out[b][q][1] += sum (f_A - f_AB)^2    (S1_d / ST_d)
+// Inputs are [nq][ld] row-major; every workgroup writes its own partial (deterministic), summed by the caller.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int SOBOL_BLOCK = 256;
+constexpr int SOBOL_MAXQ = 8;
+
+__global__ __launch_bounds__(SOBOL_BLOCK) void sobol_partial_kernel(long long m, int nq, size_t ld,
+                                                                    const double* __restrict__ fA,
+                                                                    const double* __restrict__ fB,
+                                                                    const double* __restrict__ fAB,
+                                                                    double* __restrict__ partial) {
+    __shared__ double red[2 * SOBOL_MAXQ][SOBOL_BLOCK / 64];
+    double s0[SOBOL_MAXQ], s1[SOBOL_MAXQ];
+#pragma unroll
+    for (int q = 0; q < SOBOL_MAXQ; ++q) s0[q] = s1[q] = 0.0;
+    const long long stride = (long long)gridDim.x * SOBOL_BLOCK;
+    for (long long i = (long long)blockIdx.x * SOBOL_BLOCK + threadIdx.x; i < m; i += stride) {
+#pragma unroll
+        for (int q = 0; q < SOBOL_MAXQ; ++q) {
+            if (q < nq) {
+                const double a = fA[(size_t)q * ld + i], b = fB[(size_t)q * ld + i];
+                if (fAB) {
+                    const double ab = fAB[(size_t)q * ld + i];
+                    s0[q] = fma(b, ab - a, s0[q]);
+                    s1[q] = fma(a - ab, a - ab, s1[q]);
+                } else {
+                    s0[q] += a + b;
+                    s1[q] = fma(a, a, fma(b, b, s1[q]));
+                }
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < SOBOL_MAXQ; ++q) {
+#pragma unroll
+        for (int msk = 32; msk >= 1; msk >>= 1) {
+            s0[q] += __shfl_xor(s0[q], msk);
+            s1[q] += __shfl_xor(s1[q], msk);
+        }
+        if (lane == 0) {
+            red[2 * q][wave] = s0[q];
+            red[2 * q + 1][wave] = s1[q];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * nq) {
+        double t = 0.0;
+        for (int w = 0; w < SOBOL_BLOCK / 64; ++w) t += red[threadIdx.x][w];
+        partial[(size_t)blockIdx.x * 2 * nq + threadIdx.x] = t;      // [block][q][2]
+    }
+}
+
+}  // namespace
+
+extern "C" int pem_sobol_partial_f64_dev(size_t m, int nq, size_t ld, const double* fA, const double* fB, const double* fAB,
+                                         double* partial, int n_blocks, pem_stream_t stream) {
+    if (nq < 1 || nq > SOBOL_MAXQ) return pem::fail(PEM_ERR_INVALID_ARG, "pem_sobol_partial: 1 <= nq <= %d", SOBOL_MAXQ);
+    if (n_blocks < 1 || !fA || !fB || !partial || ld < m) return pem::fail(PEM_ERR_INVALID_ARG, "pem_sobol_partial: bad arguments");
+    if (int rc = pem::check_device()) return rc;
+    hipLaunchKernelGGL(sobol_partial_kernel, dim3((unsigned)n_blocks), dim3(SOBOL_BLOCK), 0, static_cast<hipStream_t>(stream),
+                       (long long)m, nq, ld, fA, fB, fAB, partial);
+    HIP_TRY(hipGetLastError());
+    return PEM_OK;
+}

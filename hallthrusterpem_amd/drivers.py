@@ -152,24 +152,39 @@ def sobol_indices(n_base: int, seed: int = 0, qois=QOI_NAMES, priors=None, fixed
     rows = [{'V_cc': 0, 'div_angle': 1, 'T_c': 2}.get(k) for k in qois]
     if any(r is None for r in rows):
         raise ValueError(f'sobol_indices handles the scalar QoIs V_cc, div_angle, T_c; got {qois}')
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    NB = 1024                                                          # workgroups (= deterministic partial sums) per pass
+    partial = torch.empty((NB, nq, 2), dtype=torch.float64, device=dev)
+    ptr = lambda x: C.c_void_p(x.data_ptr())                           # noqa: E731
 
-    def run(batch, first, swap):
+    def block(batch, keep, first, swap):
         batch.run_mc(design, first_index=first, swap_dim=swap)         # Saltelli block generated inside the kernel
-        return batch.qoi[rows].T.clone()                               # [m][nq]
+        keep.copy_(batch.qoi[rows])                                    # [nq][m]
 
-    batch = None
+    def sums(fA, fB, fAB, m):
+        _lib.check(lib.pem_sobol_partial_f64_dev(m, nq, fA.stride(0), ptr(fA), ptr(fB), ptr(fAB) if fAB is not None else None,
+                                                 ptr(partial), NB, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        return partial.sum(dim=0)                                      # [nq][2]
+
+    batch = fA = fB = fAB = None
     for off in range(lo, hi, bs):
         m = min(bs, hi - off)
         if batch is None or batch.n != m:
-            batch = CoupledBatch(m, device=dev, profile=False)
-        fA, fB = run(batch, off, -1), run(batch, off, -2)
-        acc[0] += fA.sum(0) + fB.sum(0)
-        acc[1] += (fA * fA).sum(0) + (fB * fB).sum(0)
+            batch = CoupledBatch(m, device=dev, profile=False, thruster_qoi=False)
+            fA, fB, fAB = (torch.empty((nq, m), dtype=torch.float64, device=dev) for _ in range(3))
+        block(batch, fA, off, -1)
+        block(batch, fB, off, -2)
+        s = sums(fA, fB, None, m)
+        acc[0] += s[:, 0]
+        acc[1] += s[:, 1]
         acc[2] += 2 * m
         for j, d in enumerate(varied):
-            fAB = run(batch, off, d)
-            acc[3 + j] += (fB * (fAB - fA)).sum(0)
-            acc[3 + nd + j] += ((fA - fAB) ** 2).sum(0)
+            block(batch, fAB, off, d)
+            s = sums(fA, fB, fAB, m)
+            acc[3 + j] += s[:, 0]
+            acc[3 + nd + j] += s[:, 1]
     if world > 1:
         dist.all_reduce(acc, group=group)
     cnt = acc[2]

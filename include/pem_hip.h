@@ -157,6 +157,13 @@ int pem_sample_lhs_f64_dev(size_t n, uint64_t first_index, uint64_t n_total, uin
                            int ndim, const int32_t* kind, const double* a, const double* b, double* out,
                            size_t ld, pem_stream_t stream);
 
+/* Saltelli accumulation for the Sobol' estimators (uq.sobol_sa at scripts/pem_v0/sobol.py:113 -- uqtils, third-party,
+ * parity UNPINNED; estimators stated in hallthrusterpem_amd/drivers.py).  fA / fB / fAB: [nq][ld] QoI rows of the
+ * A, B and AB_d blocks (fAB NULL for the mean/variance sums).  partial: [n_blocks][nq][2], one deterministic partial
+ * sum per workgroup: {sum fA+fB, sum fA^2+fB^2} or {sum fB (fAB-fA), sum (fA-fAB)^2}.  nq <= 8.                    */
+int pem_sobol_partial_f64_dev(size_t m, int nq, size_t ld, const double* fA, const double* fB, const double* fAB,
+                              double* partial, int n_blocks, pem_stream_t stream);
+
 /* ---- likelihood of measured ion current density (scripts/pem_v0/mcmc.py:57-106, `jion` branch; the mirrored
  * linear interpolation of monte_carlo.py:265-270 / plume.py:142-149).  The scripts are stale and untested in the
  * reference: parity UNPINNED; formula in csrc/pem_likelihood.hip.  Sample i belongs to condition i mod n_cond.
