@@ -107,8 +107,8 @@ def read_committed_traffic(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=100)
-    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=300)
+    ap.add_argument('--warmup', type=int, default=30)
     ap.add_argument('--samples-per-gpu', type=int, default=SAMPLES_PER_GPU)
     ap.add_argument('--lanes', type=int, default=0, help='lanes per sample of the kernel (0 = library default)')
     ap.add_argument('--gather', choices=['qoi', 'full', 'none'], default='qoi',
