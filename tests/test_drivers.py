@@ -154,3 +154,28 @@ def test_rejection_of_plume_spikes():
     same, one = drivers.sample_plume_without_spikes(n, seed=13, threshold=1e9)
     assert one == 1 and torch.equal(same, raw)
     assert torch.equal(again, x)                                     # deterministic
+
+
+@pytest.mark.gpu
+def test_config1_cathode_lhs_design_on_device():
+    """BASELINE.json configs[0] end to end on the device: a 1e4-sample Latin-hypercube design over the ranges of
+    tests/test_cathode.py:19-21, generated by the HIP sampler, through cathode_coupling, against the oracle."""
+    from hallthrusterpem_amd import constants
+    from hallthrusterpem_amd.models import cathode_coupling
+    from hallthrusterpem_amd.sampling import LOGUNIFORM, UNIFORM, Design, Prior
+    from oracle import oracle_ctypes as oc
+    pri = {'P_b': Prior(LOGUNIFORM, -8.0, -4.0, 'test_cathode.py:19'), 'V_a': Prior(UNIFORM, 200.0, 400.0, ':19'),
+           'T_e': Prior(UNIFORM, 1.0, 5.0, ':20'), 'V_vac': Prior(UNIFORM, 0.0, 60.0, ':20'),
+           'Pstar': Prior(UNIFORM, 10e-6, 100e-6, ':21'), 'P_T': Prior(UNIFORM, 10e-6, 100e-6, ':21')}
+    d = Design(priors=pri, names=tuple(pri), seed=0)
+    n = 10_000
+    x = d.sample(n, method='lhs', n_total=n)
+    for i, k in enumerate(pri):                                   # one sample per stratum in every dimension
+        u = (torch.log10(x[i]) - pri[k].a) / (pri[k].b - pri[k].a) if pri[k].kind == LOGUNIFORM else (x[i] - pri[k].a) / (pri[k].b - pri[k].a)
+        cells = (u * n).floor().long().clamp_(0, n - 1).sort().values
+        assert int((cells != torch.arange(n, device=cells.device)).sum()) <= 2       # log10/10^ round trip at cell edges
+    got = cathode_coupling(d.as_dict(x))['V_cc']
+    xh = x.cpu().numpy()
+    want = oc.cathode(*[xh[i] for i in range(6)], constants.TORR_2_PA)
+    assert rel_err(got.cpu().numpy(), want) <= 1e-10
+    assert float(got.min()) >= 0 and float(got.max()) <= 100
