@@ -76,6 +76,23 @@ class CoupledBatch:
             self.inputs.stride(0), *self._out_ptrs, C.c_void_p(s.cuda_stream))
         _lib.check(rc)
 
+    def run_loglik(self, likelihood, out=None, stream=None):
+        """Coupled evaluation + `likelihood.JionLikelihood.per_sample` in one launch (`pem_coupled_loglik_f64_dev`): the
+        profile is reduced against the measurements in LDS and never written.  Sample i belongs to condition
+        i mod Ne.  Returns the (n,) per-sample sums; V_cc / div_angle / T_c / invalid are written as by `run`."""
+        import torch
+        s = torch.cuda.current_stream(self.device) if stream is None else stream
+        if out is None:
+            out = torch.empty(self.n, dtype=torch.float64, device=self.device)
+        p = lambda t: C.c_void_p(t.data_ptr())                                   # noqa: E731
+        lk = likelihood
+        rc = _lib.load().pem_coupled_loglik_f64_dev(
+            self.n, constants.TORR_2_PA, self.radius, *self._in_ptrs, lk.n_cond, lk.n_ang, p(lk.kidx), p(lk.weight),
+            p(lk.y), p(lk.inv_std), p(self.qoi[0]), p(self.qoi[1]), p(self.qoi[2]), p(out), p(self.invalid),
+            C.c_void_p(s.cuda_stream))
+        _lib.check(rc)
+        return out
+
     def outputs(self) -> dict:
         out = {'V_cc': self.qoi[0], 'div_angle': self.qoi[1], 'T_c': self.qoi[2], 'invalid': self.invalid.bool()}
         if self.I_B0 is not None:

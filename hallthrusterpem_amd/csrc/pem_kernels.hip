@@ -152,6 +152,11 @@ struct PlumeIO {
     double *j_ion, *div, *Tc;
     uint8_t* invalid;
     float* j_ion_f32;  // mixed mode: the profile is computed in fp64 and stored as fp32
+    // fused likelihood mode (JMODE 3): measurement tables [n_cond][n_ang] and the per-sample result
+    const int32_t* m_kidx;
+    const double *m_wgt, *m_y, *m_inv_std;
+    double* loglik;
+    int n_cond, n_ang;
 };
 
 struct CoupledIO {
@@ -262,6 +267,8 @@ __device__ __forceinline__ SampleIn<true> generate_sample(const McDesign& mc, lo
 //   COUPLED  cathode + thruster stages are evaluated in front of the plume (inputs from CoupledIO)
 //   JMODE    0: reduced-QoI mode, no profile;  1: stage and store the 91-point profile as fp64;
 //            2: mixed mode -- same fp64 arithmetic, profile rounded once to fp32 when it is staged
+//            3: fused likelihood -- the profile is staged in LDS only and reduced against measured current
+//               densities there (csrc/pem_likelihood.hip's formula); nothing but scalars leaves the chip
 // LDS map (doubles): shared by the workgroup: simpson[96][2] | dpoly[32*12];  per wave: params[NROWS][64] |
 // tile[S*91] | 2 (sink).  The Simpson table is padded with zero weights to L*CH <= 96 entries so the angle loop
 // needs no branch.  The den/num partial sums of a round reuse the rows of `params` that the round has consumed.
@@ -270,11 +277,12 @@ constexpr int NPARAM = 9;   // X1 X2 jcex | r0 G E (beam 1) | r0 G E (beam 2)
 constexpr int NSIMP = 96;   // >= L*CH for L in {2, 4, 8}
 constexpr int WPB = 4;      // waves per workgroup (they share the two tables and nothing else)
 template <int L>
-constexpr int param_rows() { return 2 * L > NPARAM ? 2 * L : NPARAM; }
+constexpr int param_rows() { return 2 * L > NPARAM ? 2 * L : NPARAM; }   // rows 2c, 2c+1 are reused for the Simpson partials
 constexpr int TABLE_DOUBLES = 2 * NSIMP + PEM_NDI * PEM_NDC;
 template <int L, int JMODE>
 constexpr int wave_lds_doubles() {
-    return param_rows<L>() * WAVE + (JMODE == 1 ? (WAVE / L) * NANG + 2 : JMODE == 2 ? ((WAVE / L) * NANG + 4) / 2 : 0);
+    return param_rows<L>() * WAVE +
+           ((JMODE == 1 || JMODE == 3) ? (WAVE / L) * NANG + 2 : JMODE == 2 ? ((WAVE / L) * NANG + 4) / 2 : 0);
 }
 template <int L, int JMODE>
 constexpr int fast_lds_doubles() { return TABLE_DOUBLES + WPB * wave_lds_doubles<L, JMODE>(); }
@@ -304,6 +312,7 @@ __device__ __forceinline__ void stream_store(f64x2 v, f64x2* dst) {
 
 // LDS views of one wave
 struct WaveLds {
+    const double* meas;      // fused likelihood: [n_cond*n_ang] records {weight, y, inv_std, k (integer bits)}, or nullptr
     const double2* simpson;  // [96] {cden, cnum}
     const double* poly;      // [32*12]
     double* params;          // [9][64]
@@ -442,8 +451,44 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
                     if (k0 + j < NANG) tile[s * NANG + k0 + j] = (JT)1e-20;
             }
             wave_lds_sync();
-            // the round's S*91 values are one contiguous, 16-byte aligned block of j_ion
             const long long first = t * WAVE + (long long)round * S;
+            if constexpr (JMODE == 3) {
+                static_assert(JMODE != 3 || 2 * L < param_rows<L>(), "row 2L of `params` carries the likelihood sum");
+                // measured current densities against the staged profile: lane (s, c) takes measurements c, c+L, ...
+                // of its sample's condition (sample index mod n_cond); the sample's sum goes to row 2L of `params`
+                const unsigned cond = ((unsigned)((t * WAVE) % io.n_cond) + (unsigned)(round * S + s)) % (unsigned)io.n_cond;
+                const double4* mt = reinterpret_cast<const double4*>(m.meas) + cond * (io.n_ang | 1);   // {weight, y, 1/std, k}
+                const JT* row = tile + s * NANG;
+                double acc = 0.0;
+#ifndef PEM_LOGLIK_MU
+#define PEM_LOGLIK_MU 2
+#endif
+                constexpr int MU = PEM_LOGLIK_MU;   // records in flight per lane: the k -> row[k] chain is two LDS latencies deep
+                for (int a0 = c; a0 < io.n_ang; a0 += MU * L) {
+                    double4 e[MU];
+                    double lo_v[MU], hi_v[MU];
+#pragma unroll
+                    for (int u = 0; u < MU; ++u) e[u] = mt[a0 + u * L < io.n_ang ? a0 + u * L : a0];
+#pragma unroll
+                    for (int u = 0; u < MU; ++u) {
+                        const int k = __double_as_longlong(e[u].w) & 0x7f;
+                        lo_v[u] = row[k];
+                        hi_v[u] = row[k + 1];
+                    }
+#pragma unroll
+                    for (int u = 0; u < MU; ++u) {
+                        const double model = fma(e[u].x, hi_v[u] - lo_v[u], lo_v[u]);
+                        const double z = (e[u].y - model) * e[u].z;
+                        if (a0 + u * L < io.n_ang) acc = fma(-0.5 * z, z, acc);
+                    }
+                }
+#pragma unroll
+                for (int sh = S; sh < WAVE; sh <<= 1) acc += __shfl_xor(acc, sh);   // the L chunk lanes of sample s
+                if (c == 0) params[(2 * L) * WAVE + smp] = acc;
+                wave_lds_sync();
+                continue;
+            }
+            // the round's S*91 values are one contiguous, 16-byte aligned block of j_ion
             JT* jbase;
             if constexpr (JMODE == 2) jbase = io.j_ion_f32; else jbase = io.j_ion;
             if constexpr (FULL) {
@@ -480,6 +525,9 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
     }
     double cos_div = num / den;  // plume.py:124-127
     if (cos_div == __builtin_inf()) cos_div = __builtin_nan("");
+    if constexpr (JMODE == 3) {
+        if (live) io.loglik[g] = params[(2 * L) * WAVE + lane];
+    }
     if (live) {
         stream_store1(acos(cos_div), io.div + g);
         if (have_T) stream_store1(thrust * cos_div, io.Tc + g);
@@ -507,6 +555,20 @@ __global__ __launch_bounds__(WAVE * WPB) void plume_r1_kernel(PlumeIO io, Couple
     m.poly = tab_poly;
     m.params = lds + TABLE_DOUBLES + wave * wave_lds_doubles<L, JMODE>();   // [rows][64], private to this wave
     m.tile = m.params + param_rows<L>() * WAVE;                               // [S*91] + sink
+    m.meas = nullptr;
+    if constexpr (JMODE == 3) {   // measurement tables behind the per-wave regions (vmcnt is in order: never global)
+        double* meas = lds + TABLE_DOUBLES + WPB * wave_lds_doubles<L, JMODE>();
+        const int nent = io.n_cond * io.n_ang;
+        // one 32-byte record per measurement; an odd record stride per condition spreads the conditions over the banks
+        for (int i = tid; i < nent; i += WAVE * WPB) {
+            const int r = 4 * ((i / io.n_ang) * (io.n_ang | 1) + i % io.n_ang);
+            meas[r] = io.m_wgt[i];
+            meas[r + 1] = io.m_y[i];
+            meas[r + 2] = io.m_inv_std[i];
+            meas[r + 3] = __longlong_as_double((long long)io.m_kidx[i]);
+        }
+        m.meas = meas;
+    }
 
     for (int i = tid; i < NSIMP; i += WAVE * WPB)
         tab_simpson[i] = i < NANG ? make_double2(PEM_SIMPSON_CDEN[i], PEM_SIMPSON_CNUM[i]) : make_double2(0.0, 0.0);
@@ -747,7 +809,8 @@ int fast_grid(size_t lds_bytes, long long ntiles, unsigned* grid) {
 
 template <int L, bool COUPLED, int JMODE, bool MC = false>
 int launch_r1(const PlumeIO& io, const CoupledIO& cio, hipStream_t st, const McDesign& mc = McDesign{}) {
-    const size_t lds = (size_t)fast_lds_doubles<L, JMODE>() * 8;
+    size_t lds = (size_t)fast_lds_doubles<L, JMODE>() * 8;
+    if (JMODE == 3) lds += (size_t)io.n_cond * (io.n_ang | 1) * 32;
     const long long ntiles = (io.n + WAVE - 1) / WAVE;
     unsigned grid = 0;
     if (int rc = fast_grid(lds, ntiles, &grid)) return rc;
@@ -971,6 +1034,27 @@ int pem_coupled_mc_f64_dev(size_t n, uint64_t first_index, uint64_t seed, uint32
     CoupledIO cio{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, V_cc, I_B0, T};
     hipStream_t st = static_cast<hipStream_t>(stream);
     return j_ion ? launch_r1<4, true, 1, true>(io, cio, st, mc) : launch_r1<4, true, 0, true>(io, cio, st, mc);
+}
+
+// ---- coupled + likelihood fused: the profile never leaves the chip ------------------------------------------------
+int pem_coupled_loglik_f64_dev(size_t n, double torr2pa, double radius, const double* P_b, const double* V_a,
+                               const double* T_e, const double* V_vac, const double* Pstar, const double* P_T,
+                               const double* mdot_a, const double* a_1, const double* c0, const double* c1, const double* c2,
+                               const double* c3, const double* c4, const double* c5, const double* sigma_cex, int n_cond,
+                               int n_ang, const int32_t* kidx, const double* weight, const double* y, const double* inv_std,
+                               double* V_cc, double* div_angle, double* T_c, double* loglik, uint8_t* invalid,
+                               pem_stream_t stream) {
+    if (n_cond < 1 || n_ang < 1 || (long long)n_cond * (n_ang | 1) > PEM_FUSED_LOGLIK_MAX_MEASUREMENTS)
+        return fail(PEM_ERR_INVALID_ARG, "pem_coupled_loglik: 1 <= n_cond * (n_ang | 1) <= %d", PEM_FUSED_LOGLIK_MAX_MEASUREMENTS);
+    if (n == 0) return PEM_OK;
+    if (!P_b || !V_a || !T_e || !V_vac || !Pstar || !P_T || !mdot_a || !a_1 || !c0 || !c1 || !c2 || !c3 || !c4 || !c5 ||
+        !sigma_cex || !kidx || !weight || !y || !inv_std || !V_cc || !div_angle || !T_c || !loglik)
+        return fail(PEM_ERR_INVALID_ARG, "pem_coupled_loglik: NULL array");
+    if (int rc = check_device()) return rc;
+    PlumeIO io{(long long)n, torr2pa, radius, P_b, c0, c1, c2, c3, c4, c5, sigma_cex, nullptr, nullptr, nullptr, div_angle, T_c, invalid, nullptr,
+               kidx, weight, y, inv_std, loglik, n_cond, n_ang};
+    CoupledIO cio{V_a, T_e, V_vac, Pstar, P_T, mdot_a, a_1, V_cc, nullptr, nullptr};
+    return launch_r1<4, true, 3>(io, cio, static_cast<hipStream_t>(stream));
 }
 
 // ---- coupled, mixed precision: fp64 arithmetic, the 91-point profile stored as fp32 -----------------

@@ -174,6 +174,19 @@ int pem_jion_loglik_f64_dev(size_t n, int n_cond, int n_ang, const int32_t* kidx
                             const double* y, const double* inv_std, const double* j_ion, double* loglik,
                             pem_stream_t stream);
 
+/* pem_coupled_f64_dev + pem_jion_loglik_f64_dev in one launch: the 91-point profile is staged in LDS, reduced against
+ * the measurements there and never written (152 bytes per evaluation).  Same per-sample results as the two-launch
+ * pipeline up to the summation order of the partial sums.  n_cond * (n_ang | 1) <= PEM_FUSED_LOGLIK_MAX_MEASUREMENTS
+ * (LDS table).                                                                                                       */
+#define PEM_FUSED_LOGLIK_MAX_MEASUREMENTS 1024
+int pem_coupled_loglik_f64_dev(size_t n, double torr2pa, double radius, const double* P_b, const double* V_a,
+                               const double* T_e, const double* V_vac, const double* Pstar, const double* P_T,
+                               const double* mdot_a, const double* a_1, const double* c0, const double* c1,
+                               const double* c2, const double* c3, const double* c4, const double* c5,
+                               const double* sigma_cex, int n_cond, int n_ang, const int32_t* kidx,
+                               const double* weight, const double* y, const double* inv_std, double* V_cc,
+                               double* div_angle, double* T_c, double* loglik, uint8_t* invalid, pem_stream_t stream);
+
 /* ---- SVD compression / reconstruction of field QoIs (fp64 MFMA) --------------------------------
  * Stand in for amisc `Compression(method='svd')` on `j_ion` (norm log10) and `u_ion` (norm linear(1e-3)):
  * scripts/pem_v0/pem_v0_SPT-100.yml:207-214,273-280, scripts/gen_data.py:261-294.  Third-party in the

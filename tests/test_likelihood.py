@@ -35,3 +35,33 @@ def test_loglik_matches_numpy():
     with pytest.raises(ValueError):
         JionLikelihood(np.array([[2.0]]), np.array([[1.0]]), np.array([[1.0]]))
     assert lk.per_sample(torch.empty((0, 91), dtype=torch.float64, device='cuda')).shape == (0,)
+
+
+@pytest.mark.parametrize('n', [8 * 37 * 5, 100003])
+def test_fused_coupled_loglik_matches_two_launch_pipeline(n):
+    """pem_coupled_loglik_f64_dev (profile reduced in LDS) == pem_coupled_f64_dev followed by pem_jion_loglik_f64_dev."""
+    import torch
+    from hallthrusterpem_amd.batch import CoupledBatch
+    from hallthrusterpem_amd.likelihood import JionLikelihood
+    from hallthrusterpem_amd.sampling import Design
+    rng = np.random.default_rng(11)
+    Ne, Na = 8, 43
+    alpha = np.sort(rng.uniform(-np.pi / 2, np.pi / 2, (Ne, Na)), axis=1)
+    alpha[0, 0], alpha[0, -1], alpha[1, 3] = -np.pi / 2, np.pi / 2, 0.0
+    y = rng.lognormal(1.0, 1.0, (Ne, Na))
+    lk = JionLikelihood(alpha, y, 0.2 * y + 0.05)
+    ref = CoupledBatch(n, profile=True, thruster_qoi=False)
+    Design(seed=21).fill(ref.inputs, method='mc')
+    ref.inputs[10, 5:9], ref.inputs[11, 5:9] = 0.0, -1.0     # alpha1 = c3 <= 0: invalid, profile 1e-20 in both paths
+    ref.run()
+    want = lk.per_sample(ref.j_ion)
+    fused = CoupledBatch(n, profile=False, thruster_qoi=False)
+    fused.inputs.copy_(ref.inputs)
+    got = fused.run_loglik(lk)
+    torch.cuda.synchronize()
+    w, g = want.cpu().numpy(), got.cpu().numpy()
+    assert np.array_equal(np.isnan(w), np.isnan(g))
+    ok = ~np.isnan(w)
+    assert np.max(np.abs(g[ok] - w[ok]) / np.maximum(1.0, np.abs(w[ok]))) < 1e-12
+    assert torch.equal(ref.qoi, fused.qoi) and torch.equal(ref.invalid, fused.invalid)
+    assert ref.invalid[5:9].all()

@@ -21,3 +21,24 @@ for _ in range(20): lk.per_sample(j)
 b.record(); torch.cuda.synchronize()
 ms = a.elapsed_time(b) / 20
 print(f'jion_loglik: n={n} Ne={Ne} Na={Na}: {ms*1e3:.1f} us per call, {n*736/ms/1e6:.0f} GB/s algorithmic (736 B/sample), {n/ms/1e3:.0f} M samples/s')
+
+# fused: coupled evaluation + likelihood in one launch, profile never written (152 B per evaluation)
+from hallthrusterpem_amd.batch import CoupledBatch
+from hallthrusterpem_amd.sampling import Design
+two = CoupledBatch(n, profile=True, thruster_qoi=False)
+Design(seed=2).fill(two.inputs)
+fused = CoupledBatch(n, profile=False, thruster_qoi=False)
+fused.inputs.copy_(two.inputs)
+out = torch.empty(n, dtype=torch.float64, device='cuda')
+def t(fn, reps=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(reps): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+ms2 = t(lambda: (two.run(), lk.per_sample(two.j_ion)))
+ms1 = t(lambda: fused.run_loglik(lk, out=out))
+ms0 = t(lambda: fused.run())
+print(f'coupled -> loglik, two launches: {ms2*1e3:.1f} us; fused pem_coupled_loglik: {ms1*1e3:.1f} us '
+      f'({n/ms1/1e6:.2f} G evals/s); coupled without profile: {ms0*1e3:.1f} us')
