@@ -112,7 +112,135 @@ __global__ __launch_bounds__(BLOCK) void jion_loglik_kernel(long long n, int n_c
     }
 }
 
+// ---- marginalisation over nuisance draws (mcmc.py:100-107) and the prior (mcmc.py:110-121) ----------------------
+// One workgroup per chain k: s[m] = sum_e ll[k][m][e] (+ the discharge-current weight of mcmc.py:102-104 with the
+// test double's I_d = (q/m_i) mdot_a / (1 - 2 a_1), tests/sim_hallthruster.jl:35-40), then a streaming
+// log-sum-exp over m held as (max, sum of exp(s - max)) pairs.  NaN in any s makes the result NaN, all -inf gives -inf
+// -- as numpy's max-shifted form in the reference.  With `log_prior` given the output is the log posterior:
+// prior + likelihood, -inf where the prior is -inf or the likelihood NaN.
+struct Lse {
+    double mx, acc;
+};
+
+__device__ __forceinline__ Lse lse_push(Lse a, double s) {
+    if (s > a.mx) {
+        a.acc = (a.acc == 0.0 ? 0.0 : a.acc * exp(a.mx - s)) + 1.0;
+        a.mx = s;
+    } else if (s != -__builtin_inf()) {
+        a.acc += exp(s - a.mx);   // NaN s lands here and poisons acc
+    }
+    return a;
+}
+
+__device__ __forceinline__ Lse lse_merge(Lse a, Lse b) {
+    const double m = fmax(a.mx, b.mx);
+    const double ta = a.acc == 0.0 ? 0.0 : a.acc * exp(a.mx - m);
+    const double tb = b.acc == 0.0 ? 0.0 : b.acc * exp(b.mx - m);
+    return Lse{m, ta + tb};
+}
+
+__global__ __launch_bounds__(BLOCK) void loglik_marginal_kernel(int n_draws, int n_cond, const double* __restrict__ ll,
+                                                                const double* __restrict__ mdot_a,
+                                                                const double* __restrict__ a_1, double discharge,
+                                                                double inv_sigma, const double* __restrict__ log_prior,
+                                                                double* __restrict__ out) {
+    __shared__ Lse part[WAVES];
+    const long long base = (long long)blockIdx.x * n_draws * n_cond;
+    Lse st{-__builtin_inf(), 0.0};
+    for (int m = threadIdx.x; m < n_draws; m += BLOCK) {
+        const long long row = base + (long long)m * n_cond;
+        double s = 0.0;
+        for (int e = 0; e < n_cond; ++e) s += ll[row + e];
+        if (mdot_a) {
+            double w = 0.0;
+            for (int e = 0; e < n_cond; ++e) {
+                const double i_d = (1.6e-19 / 2.18e-25) * mdot_a[row + e] / (1.0 - a_1[row + e] * 2.0);
+                const double z = (discharge - i_d) * inv_sigma;
+                w = fma(-0.5 * z, z, w);
+            }
+            s += w;
+        }
+        st = lse_push(st, s);
+    }
+    for (int sh = 32; sh >= 1; sh >>= 1) st = lse_merge(st, Lse{__shfl_xor(st.mx, sh), __shfl_xor(st.acc, sh)});
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = st;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < WAVES; ++w) st = lse_merge(st, part[w]);
+        double r = st.mx + log(st.acc);            // all -inf: -inf + log(0) = -inf
+        if (st.acc != st.acc) r = st.acc;          // NaN
+        if (log_prior) {
+            const double lp = log_prior[blockIdx.x];
+            r = (lp - lp == 0.0 && r == r) ? lp + r : -__builtin_inf();
+        }
+        out[blockIdx.x] = r;
+    }
+}
+
+struct PriorTable {
+    int32_t kind[PEM_SAMPLE_MAX_DIM];
+    double a[PEM_SAMPLE_MAX_DIM], b[PEM_SAMPLE_MAX_DIM];
+};
+
+__global__ void log_prior_kernel(long long n, int ndim, PriorTable t, const double* __restrict__ theta,
+                                 double* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double lp = 0.0;
+    for (int d = 0; d < ndim; ++d) {
+        const double x = theta[i * ndim + d], a = t.a[d], b = t.b[d];
+        double v;
+        if (t.kind[d] == PEM_DIST_UNIFORM) {
+            v = (x >= a && x <= b) ? -log(b - a) : -__builtin_inf();
+        } else if (t.kind[d] == PEM_DIST_LOGUNIFORM) {   // density of 10^U(a, b): 1 / (x ln10 (b - a))
+            v = (x >= pow(10.0, a) && x <= pow(10.0, b)) ? -log(x) - log(2.302585092994045684 * (b - a)) : -__builtin_inf();
+        } else {
+            const double z = (x - a) / b;
+            v = -0.5 * z * z - log(b * 2.5066282746310002);
+        }
+        lp += v;
+    }
+    out[i] = lp;
+}
+
 }  // namespace
+
+extern "C" int pem_loglik_marginal_f64_dev(size_t n_chains, int n_draws, int n_cond, const double* loglik,
+                                           const double* mdot_a, const double* a_1, double discharge_current,
+                                           double discharge_sigma, const double* log_prior, double* out,
+                                           pem_stream_t stream) {
+    if (n_draws < 1 || n_cond < 1) return pem::fail(PEM_ERR_INVALID_ARG, "pem_loglik_marginal: need n_draws, n_cond >= 1");
+    if (n_chains == 0) return PEM_OK;
+    if (!loglik || !out || (mdot_a && !a_1)) return pem::fail(PEM_ERR_INVALID_ARG, "pem_loglik_marginal: NULL array");
+    if (mdot_a && !(discharge_sigma > 0.0)) return pem::fail(PEM_ERR_INVALID_ARG, "pem_loglik_marginal: discharge_sigma must be > 0");
+    if (n_chains > 0x7fffffffull) return pem::fail(PEM_ERR_INVALID_ARG, "pem_loglik_marginal: too many chains");
+    if (int rc = pem::check_device()) return rc;
+    hipLaunchKernelGGL(loglik_marginal_kernel, dim3((unsigned)n_chains), dim3(BLOCK), 0, static_cast<hipStream_t>(stream),
+                       n_draws, n_cond, loglik, mdot_a, a_1, discharge_current, mdot_a ? 1.0 / discharge_sigma : 0.0, log_prior,
+                       out);
+    HIP_TRY(hipGetLastError());
+    return PEM_OK;
+}
+
+extern "C" int pem_log_prior_f64_dev(size_t n, int ndim, const int32_t* kind, const double* a, const double* b,
+                                     const double* theta, double* out, pem_stream_t stream) {
+    if (ndim < 1 || ndim > PEM_SAMPLE_MAX_DIM) return pem::fail(PEM_ERR_INVALID_ARG, "pem_log_prior: 1 <= ndim <= %d", PEM_SAMPLE_MAX_DIM);
+    if (!kind || !a || !b) return pem::fail(PEM_ERR_INVALID_ARG, "pem_log_prior: NULL prior table");
+    PriorTable t{};
+    for (int d = 0; d < ndim; ++d) {
+        if (kind[d] < PEM_DIST_UNIFORM || kind[d] > PEM_DIST_NORMAL) return pem::fail(PEM_ERR_INVALID_ARG, "pem_log_prior: unknown distribution %d", kind[d]);
+        t.kind[d] = kind[d];
+        t.a[d] = a[d];
+        t.b[d] = b[d];
+    }
+    if (n == 0) return PEM_OK;
+    if (!theta || !out) return pem::fail(PEM_ERR_INVALID_ARG, "pem_log_prior: NULL array");
+    if (int rc = pem::check_device()) return rc;
+    hipLaunchKernelGGL(log_prior_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       (long long)n, ndim, t, theta, out);
+    HIP_TRY(hipGetLastError());
+    return PEM_OK;
+}
 
 extern "C" int pem_jion_loglik_f64_dev(size_t n, int n_cond, int n_ang, const int32_t* kidx, const double* weight,
                                        const double* y, const double* inv_std, const double* j_ion, double* loglik,

@@ -187,6 +187,19 @@ int pem_coupled_loglik_f64_dev(size_t n, double torr2pa, double radius, const do
                                const double* weight, const double* y, const double* inv_std, double* V_cc,
                                double* div_angle, double* T_c, double* loglik, uint8_t* invalid, pem_stream_t stream);
 
+/* Marginal likelihood over nuisance draws and the prior of the calibration parameters (mcmc.py:100-121; unpinned).
+ * loglik: [n_chains][n_draws][n_cond] per-sample sums (pem_jion_loglik / pem_coupled_loglik output).
+ * out[k] = logsumexp_m( sum_e loglik[k][m][e] + sum_e -0.5 ((discharge_current - I_d[k][m][e]) / discharge_sigma)^2 ),
+ * I_d = (q/m_i) mdot_a / (1 - 2 a_1) of the analytic thruster test double; mdot_a NULL drops the discharge term.
+ * log_prior (NULL or [n_chains]): out becomes the log posterior, -inf where the prior is or the likelihood is NaN. */
+int pem_loglik_marginal_f64_dev(size_t n_chains, int n_draws, int n_cond, const double* loglik, const double* mdot_a,
+                                const double* a_1, double discharge_current, double discharge_sigma,
+                                const double* log_prior, double* out, pem_stream_t stream);
+/* out[i] = sum_d log pdf_d(theta[i][d]) for the PEM_DIST_* table (kind, a, b: host arrays, ndim <= 32); -inf outside
+ * the support of a uniform / log-uniform variable.                                                                 */
+int pem_log_prior_f64_dev(size_t n, int ndim, const int32_t* kind, const double* a, const double* b,
+                          const double* theta, double* out, pem_stream_t stream);
+
 /* ---- SVD compression / reconstruction of field QoIs (fp64 MFMA) --------------------------------
  * Stand in for amisc `Compression(method='svd')` on `j_ion` (norm log10) and `u_ion` (norm linear(1e-3)):
  * scripts/pem_v0/pem_v0_SPT-100.yml:207-214,273-280, scripts/gen_data.py:261-294.  Third-party in the
