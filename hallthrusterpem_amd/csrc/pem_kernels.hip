@@ -415,19 +415,20 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
         constexpr int PF = 6;
         double2 wq[CH];
 #pragma unroll
-        for (int j = 0; j < PF && j < CH; ++j) wq[j] = my_w[j];
+        for (int j = 0; WRITE_J && j < PF && j < CH; ++j) wq[j] = my_w[j];
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
-            if (j + PF < CH) wq[j + PF] = my_w[j + PF];
+            if constexpr (!WRITE_J) wq[j] = my_w[j];   // no tile stores in between: the compiler schedules the reads
+            else if (j + PF < CH) wq[j + PF] = my_w[j + PF];
             const double f = X1 + X2;     // j_beam + j_scat
             const double ji = f + jcex;   // plume.py:102
             if ((L - 1) * CH + j < NANG) {  // an angle every chunk has (compile-time after unrolling)
                 if constexpr (WRITE_J) tile[s * NANG + k0 + j] = (JT)ji;
-                lo = fmin(lo, ji);
+                lo = fmin(lo, WRITE_J ? ji : f);
             } else {                        // past 90 degrees in the last chunk: store to the sink, skip the min
                 const bool in_range = k0 + j < NANG;
                 if constexpr (WRITE_J) tile[in_range ? s * NANG + k0 + j : TILE] = (JT)ji;
-                lo = fmin(lo, in_range ? ji : __builtin_inf());
+                lo = fmin(lo, in_range ? (WRITE_J ? ji : f) : __builtin_inf());
             }
             den = fma(wq[j].x, f, den);
             num = fma(wq[j].y, f, num);
@@ -439,8 +440,9 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
         // this round has read its nine parameter rows of sample `smp`: rows 2c, 2c+1 now carry the partial sums
         params[(2 * c) * WAVE + smp] = den;
         params[(2 * c + 1) * WAVE + smp] = num;
-        // plume.py:105: invalid if alpha1 <= 0 or any j_ion <= 0 (NaN compares false)
-        unsigned long long bad = __ballot(lo <= 0.0);
+        // plume.py:105: invalid if alpha1 <= 0 or any j_ion <= 0 (NaN compares false).  Without a stored profile
+        // the minimum runs over f and j_cex is added once: rounding is monotonic, min_k fl(f_k + c) = fl(min_k f_k + c).
+        unsigned long long bad = __ballot((WRITE_J ? lo : lo + jcex) <= 0.0);
 #pragma unroll
         for (int sh = S; sh < WAVE; sh <<= 1) bad |= bad >> sh;   // fold the L chunk lanes of a sample onto bit s
         bad = (bad | (a1_nonpos >> (round * S))) & ((S == 64) ? ~0ull : ((1ull << S) - 1));
