@@ -24,6 +24,7 @@
 #include <cstdint>
 
 #include "pem_common.h"
+#include "pem_math.h"
 #include "pem_hip.h"
 
 namespace {
@@ -40,13 +41,13 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 // afterwards (the "none" mode then ran no faster than it would with the transcendental in it).
 template <int MODE>
 __device__ __forceinline__ double norm_fwd(double scale, double x) {
-    if constexpr (MODE == PEM_NORM_LOG10) return log10(x);
+    if constexpr (MODE == PEM_NORM_LOG10) return pem::pem_log10(x);
     else if constexpr (MODE == PEM_NORM_LINEAR) return x * scale;
     else return x;
 }
 template <int MODE>
 __device__ __forceinline__ double norm_inv(double scale, double y) {
-    if constexpr (MODE == PEM_NORM_LOG10) return exp10(y);
+    if constexpr (MODE == PEM_NORM_LOG10) return pem::pem_exp10(y);
     else if constexpr (MODE == PEM_NORM_LINEAR) return y / scale;
     else return y;
 }
@@ -138,8 +139,8 @@ __global__ __launch_bounds__(BLOCK) void svd_compress_kernel(long long n, int do
         const double* ap = a_base;
         const f64x2* bp = b_base;
 #pragma unroll 4
-        for (int step = 0; step < ksteps; ++step) {
-            const double a = *ap;             // k >= dof only in the last step: next row / zeroed slack, times a zero row
+        for (int step = 0; step < ksteps - 1; ++step) {
+            const double a = *ap;
             ap += 4;
 #pragma unroll
             for (int j = 0; j < RT; j += 2) {
@@ -148,6 +149,16 @@ __global__ __launch_bounds__(BLOCK) void svd_compress_kernel(long long n, int do
                 if (j + 1 < RT) acc[j + 1] = fma(a, b.y, acc[j + 1]);
             }
             bp += 32;                         // 4 basis rows of 16 doubles
+        }
+        {   // last step: k >= dof would read the next sample's first values (or slack) against a zero basis row --
+            // masked, because 0 * inf = NaN would let one sample's non-finite value poison its neighbour's latents
+            const double a = quad + 4 * (ksteps - 1) < dof ? *ap : 0.0;
+#pragma unroll
+            for (int j = 0; j < RT; j += 2) {
+                const f64x2 b = bp[j >> 1];
+                acc[j] = fma(a, b.x, acc[j]);
+                if (j + 1 < RT) acc[j + 1] = fma(a, b.y, acc[j + 1]);
+            }
         }
 #pragma unroll
         for (int j = 0; j < RT; ++j) {

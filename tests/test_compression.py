@@ -59,3 +59,45 @@ def test_fit_rank_from_reconstruction_tol_on_plume_profiles():
     assert float((eye - torch.eye(c.rank, device=eye.device, dtype=eye.dtype)).abs().max()) < 1e-12
     z = c.compress(j[:1000])
     assert float((c.compress(c.reconstruct(z)) - z).abs().max()) < 1e-9
+
+
+def test_fused_log10_and_exp10_norms_elementwise():
+    """csrc/pem_math.h through the C ABI: with unit vectors as the basis, latent[:, r] = log10(field[:, r]) and
+    field[:, r] = 10**latent[:, r] -- every element against numpy, including the arguments that take the library path."""
+    import torch
+    from hallthrusterpem_amd.compression import SVDCompression
+    rng = np.random.default_rng(12)
+    dof, rank, n = 91, 16, 40_000
+    basis = np.zeros((dof, rank))
+    basis[np.arange(rank), np.arange(rank)] = 1.0
+    c = SVDCompression(norm='log10', rank=rank)
+    c.basis = torch.from_numpy(basis).cuda()
+    x = np.ones((n, dof))
+    x[:, :rank] = 10.0 ** rng.uniform(-300, 300, (n, rank))
+    x[0, :rank] = [1.0, 10.0, 100.0, 1e-20, 0.5, 2.0, 1.4142135623730951, 1.4142135623730954, 0.9999999999999999,
+                   1.0000000000000002, 5e-324, 2.2250738585072014e-308, 1.7976931348623157e308, 3.0, 7.0, 1e22]
+    x[1:6, 0] = [0.0, -0.0, -1.0, np.inf, np.nan]          # a special value makes its row's other columns 0 * inf = NaN
+    with np.errstate(divide='ignore', invalid='ignore'):
+        want = np.log10(x[:, :rank])
+    got = c.compress(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert np.array_equal(got[1:6, 0], [-np.inf, -np.inf, np.nan, np.inf, np.nan], equal_nan=True)
+    got, want = np.delete(got, slice(1, 6), 0), np.delete(want, slice(1, 6), 0)
+    ulp = np.abs(got - want) / np.spacing(np.maximum(np.abs(want), 1e-300))
+    assert ulp.max() <= 2.0
+    assert np.array_equal(got[0, :3], [0.0, 1.0, 2.0]) and got[0, 3] == -20.0
+
+    z = rng.uniform(-299.0, 299.0, (n, rank))
+    z[0] = [0.0, 1.0, 2.0, -20.0, 0.5, -0.5, 22.0, -300.0, 300.0, 308.0, -308.0, -320.0, 309.0, -330.0, 3.0, -3.0]
+    z[1:4, 0] = [np.nan, np.inf, -np.inf]                  # (a non-finite latent makes the rest of its row 0 * inf = NaN)
+    with np.errstate(over='ignore'):
+        want = np.power(10.0, z)
+    got = c.reconstruct(torch.from_numpy(z).cuda()).cpu().numpy()
+    assert np.isnan(got[1, 0]) and got[2, 0] == np.inf and got[3, 0] == 0.0
+    got, want = np.delete(got, slice(1, 4), 0), np.delete(want, slice(1, 4), 0)
+    assert np.array_equal(got[:, rank:], np.ones((n - 3, dof - rank)))
+    got = got[:, :rank]
+    fin = np.isfinite(want) & (want > 1e-300)
+    assert np.array_equal(np.isinf(got), np.isinf(want)) and not np.isnan(got).any()
+    assert np.max(np.abs(got[fin] - want[fin]) / want[fin]) <= 4.5e-16
+    assert got[0, 0] == 1.0 and got[0, 1] == 10.0 and got[0, 2] == 100.0 and got[0, 12] == np.inf
+    assert got[0, 11] == pytest.approx(1e-320, rel=1e-3) and got[0, 13] == 0.0      # denormal result, underflow
