@@ -31,10 +31,11 @@ class SVDCompression:
         import torch
         return torch.log10(x) if self.norm == NORM_LOG10 else (x * self.scale if self.norm == NORM_LINEAR else x)
 
-    def fit(self, data):
-        """data: [num_samples][dof] CUDA tensor of RAW field values (the norm is applied here)."""
+    def fit(self, data, normalized: bool = False):
+        """data: [num_samples][dof] CUDA tensor of RAW field values (the norm is applied here), or of already
+        normalised ones (`normalized=True`, the data matrix of gen_data.py:287-289)."""
         import torch
-        a = self.normalize(data.double())
+        a = data.double() if normalized else self.normalize(data.double())
         _, s, vh = torch.linalg.svd(a, full_matrices=False)
         energy = torch.cumsum(s * s, 0) / torch.sum(s * s)
         err = torch.sqrt(torch.clamp(1.0 - energy, min=0.0))          # relative Frobenius error keeping r = i+1 vectors

@@ -1,7 +1,8 @@
 """Sampling-loop drivers: forward UQ, data generation with NaN/IQR filtering, Sobol' sensitivity.
 
 These follow the SHAPE of the reference's drivers:
-  * `generate_data`   scripts/gen_data.py:218-258  sample_inputs -> predict -> normalise -> NaN + IQR masks
+  * `generate_data`, `process_compression`   scripts/gen_data.py:218-294 on a `system.PemV0System`
+  * `generate_data_on_device`                the same data set, batched, without the system object
   * `filter_outputs`  scripts/gen_data.py:125-174  (pinned: tests/golden/filter_outputs.npz holds the reference's
                       own `_filter_outputs` results, extracted and run by tests/golden/make_golden.py)
   * `forward_uq`      scripts/pem_v0/monte_carlo.py:63-300  (Ns samples -> predict -> statistics)
@@ -105,13 +106,65 @@ def forward_uq(n: int, seed: int = 0, method: str = 'mc', profile: bool = False,
     return out
 
 
-def generate_data(n: int, seed: int = 0, description: str = 'test_set', method: str = 'mc', iqr_factor: float = 1.5,
-                  batch_size: int = 1 << 20, device=None):
-    """The `generate_data` step of gen_data.py:218-258 for the coupled PEM-v0 graph: sample, evaluate the true
-    models, normalise outputs as the YAML declares (`j_ion`: log10, yml:273-280), compute NaN / IQR masks.
+def generate_data(system, description: str, num_samples: int = 500, executor=None, verbose: bool = False,
+                  iqr_factor: float = 1.5, device_resident: bool = False):
+    """gen_data.py:218-258, same signature, on a `system.PemV0System`: sample the input space (calibration and
+    nuisance variables from their pdfs), evaluate the true models, normalise the outputs as their variables declare,
+    compute the NaN / IQR masks and pickle `{description: (samples, outputs), 'nan_idx', 'outlier_idx', 'iqr_factor'}`
+    to `system.root_dir/description/description.pkl` (when the system has a root_dir).
 
-    Returns the same dictionary layout the reference pickles:
-    `{description: (samples, outputs), 'nan_idx': ..., 'outlier_idx': ..., 'iqr_factor': ...}` with CUDA tensors."""
+    device_resident: keep samples and outputs as CUDA tensors (no host copy, no pickle) -- for sizes where the
+    0.75 KB per sample of profile should not cross PCIe; `j_ion_coords` is then omitted."""
+    import os
+    import pickle
+    from .system import COORDS_STR_ID, to_model_dataset
+    if getattr(system, 'logger', None) is not None:
+        system.logger.info(f'Generating {description} data for {system.name} -- {num_samples} samples...')
+    if system.root_dir is not None and not device_resident:
+        os.mkdir(system.root_dir / description)                      # raises if it exists, as the reference does
+    samples = system.sample_inputs(num_samples, normalize=True, use_pdf=['calibration', 'nuisance'],
+                                   as_tensor=device_resident)
+    outputs = system.predict(samples, use_model='best', model_dir=None if system.root_dir is None else
+                             system.root_dir / description, executor=executor, verbose=verbose)
+    if device_resident:
+        outputs = {k: v for k, v in outputs.items() if not k.endswith(COORDS_STR_ID)}
+    samples, coords = to_model_dataset(samples, system.inputs())
+    samples.update(coords)
+    norm_outputs = {var.name: var.normalize(outputs[var.name]) for var in system.outputs() if var in outputs}
+    nan_idx, outlier_idx = filter_outputs(norm_outputs, iqr_factor=iqr_factor)
+    dump = {description: (samples, outputs), 'nan_idx': nan_idx, 'outlier_idx': outlier_idx, 'iqr_factor': iqr_factor}
+    if system.root_dir is not None and not device_resident:
+        with open(system.root_dir / description / f'{description}.pkl', 'wb') as fd:
+            pickle.dump(dump, fd)
+    return dump
+
+
+def process_compression(system, data: dict, discard_outliers: bool = False):
+    """gen_data.py:261-294: compute the SVD maps of the field outputs from the 'compression' data set and save the
+    system.  NaN samples are always dropped, IQR outliers only with `discard_outliers`."""
+    from .system import COORDS_STR_ID
+    outputs = data['compression'][1]
+    discard = discard_mask(data['nan_idx'], data['outlier_idx'], discard_outliers=discard_outliers)
+    keep = ~discard
+    for var in system.outputs():
+        if var.compression is None:
+            continue
+        coords = outputs.get(f'{var}{COORDS_STR_ID}')
+        if coords is not None:
+            var.compression.coords = coords[0]                        # gen_data.py:281: all coords are the same
+        if var.compression.method.lower() != 'svd':
+            raise ValueError(f"Compression method '{var.compression.method}' not supported.")
+        var.compression.compute_map({f: var.normalize(outputs[f][keep]) for f in var.compression.fields})
+    if system.root_dir is not None:
+        (system.root_dir / 'compression').mkdir(exist_ok=True)
+        system.save_to_file(f'{system.name}_compression.pkl', system.root_dir / 'compression')
+    return system
+
+
+def generate_data_on_device(n: int, seed: int = 0, description: str = 'test_set', method: str = 'mc',
+                            iqr_factor: float = 1.5, batch_size: int = 1 << 20, device=None):
+    """`generate_data` without the system object, batched (fused sampling + evaluation kernel, any n): returns the
+    same dictionary layout with CUDA tensors."""
     import torch
     res = forward_uq(n, seed=seed, method=method, profile=True, keep_profile=True, batch_size=batch_size, device=device)
     design = sampling.Design(seed=seed)

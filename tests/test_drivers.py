@@ -61,7 +61,7 @@ def test_forward_uq_matches_oracle_on_device_design():
 
 @pytest.mark.gpu
 def test_generate_data_layout_and_masks():
-    d = drivers.generate_data(20_000, seed=5, description='compression')
+    d = drivers.generate_data_on_device(20_000, seed=5, description='compression')
     samples, outputs = d['compression']
     assert set(samples) >= {'P_b', 'c0', 'sigma_cex'} and outputs['j_ion'].shape == (20_000, 91)
     assert d['iqr_factor'] == 1.5 and set(d['nan_idx']) == set(outputs) == set(d['outlier_idx'])

@@ -1,0 +1,108 @@
+"""`system.PemV0System` -- the amisc.System call signature the reference's drivers use -- and
+the drivers written against it (`drivers.generate_data`, `drivers.process_compression`; gen_data.py:218-294).
+amisc is absent: the facade is unpinned; the model results under it are held to the oracle."""
+import pickle
+
+import numpy as np
+import pytest
+
+from hallthrusterpem_amd.models.coupled import COUPLED_INPUTS
+from hallthrusterpem_amd.system import COORDS_STR_ID, Variable, VariableList, to_model_dataset
+
+
+def test_variable_is_name_like_and_normalises():
+    v = Variable('c4', 'calibration', norm='log10')
+    s = Variable('Pstar', 'calibration', norm=('linear', 1e6))
+    d = {'c4': 1, 'j_ion': 2}
+    assert v in d and s not in d and d[v] == 1 and str(v) == 'c4' and v == 'c4' and v == Variable('c4')
+    x = np.array([1e18, 1e20, 1e22])
+    assert np.array_equal(v.normalize(x), [18.0, 20.0, 22.0]) and np.allclose(v.normalize(v.normalize(x), denorm=True), x, rtol=1e-15)
+    assert np.allclose(s.normalize(np.array([2e-5])), [20.0]) and np.allclose(s.normalize(np.array([20.0]), denorm=True), [2e-5])
+    assert Variable('T_e').normalize(x) is x
+    vl = VariableList([v, s])
+    assert vl['Pstar'] is s and vl[0] is v and 'c4' in vl and 'zz' not in vl
+    phys, coords = to_model_dataset({'c4': np.array([20.0]), 'Pstar': np.array([20.0]), 'other': 3}, vl)
+    assert coords == {} and phys['c4'][0] == 1e20 and np.isclose(phys['Pstar'][0], 2e-5) and phys['other'] == 3
+
+
+@pytest.mark.gpu
+def test_sample_inputs_follow_the_variable_table():
+    from hallthrusterpem_amd.system import PemV0System
+    sys_ = PemV0System(seed=3)
+    assert [str(v) for v in sys_.inputs()] == list(COUPLED_INPUTS)
+    assert {v.category for v in sys_.inputs()} == {'operating', 'calibration', 'nuisance'}
+    a = sys_.sample_inputs(5000, normalize=True, use_pdf=['calibration', 'nuisance'])
+    b = sys_.sample_inputs((7, 11), normalize=False)
+    assert set(a) == set(COUPLED_INPUTS) and all(v.shape == (5000,) for v in a.values()) and b['P_b'].shape == (7, 11)
+    assert -8 <= a['P_b'].min() and a['P_b'].max() <= -4 and 18 <= a['c4'].min() and a['c4'].max() <= 22     # log10 norm
+    assert 10 <= a['Pstar'].min() and a['Pstar'].max() <= 100                                                # linear(1e6)
+    assert 1e-8 <= b['P_b'].min() and b['P_b'].max() <= 1e-4 and 200 <= b['V_a'].min() and b['V_a'].max() <= 400
+    c = sys_.sample_inputs(5000, normalize=True)
+    assert not np.array_equal(a['c0'], c['c0'])                                # the design continues, it does not restart
+    t = sys_.sample_inputs(16, as_tensor=True)
+    assert t['c0'].is_cuda
+
+
+@pytest.mark.gpu
+def test_generate_data_and_process_compression_like_gen_data(tmp_path):
+    import torch
+    from oracle import oracle_ctypes as oc
+    from hallthrusterpem_amd import constants, drivers
+    from hallthrusterpem_amd.system import PemV0System
+    system = PemV0System(root_dir=tmp_path, seed=11)
+    data = drivers.generate_data(system, 'compression', num_samples=3000)
+    with open(tmp_path / 'compression' / 'compression.pkl', 'rb') as fd:
+        loaded = pickle.load(fd)
+    assert set(loaded) == {'compression', 'nan_idx', 'outlier_idx', 'iqr_factor'}
+    samples, outputs = loaded['compression']
+    assert set(samples) == set(COUPLED_INPUTS) and outputs['j_ion'].shape == (3000, 91)
+    assert outputs['j_ion' + COORDS_STR_ID].shape == (3000,) and outputs['j_ion' + COORDS_STR_ID][5].shape == (91,)
+    ref = oc.coupled(samples, torr2pa=constants.TORR_2_PA)                    # the samples are in physical units
+    for k in ('V_cc', 'div_angle', 'T_c'):
+        assert np.allclose(outputs[k], ref[k], rtol=1e-10, atol=0)
+    assert np.allclose(outputs['j_ion'], ref['j_ion'].reshape(3000, 91), rtol=1e-10, atol=0)
+    assert set(loaded['nan_idx']) == {'V_cc', 'I_B0', 'T', 'j_ion', 'div_angle', 'T_c'}
+    with pytest.raises(FileExistsError):
+        drivers.generate_data(system, 'compression', num_samples=10)
+
+    drivers.process_compression(system, data)
+    comp = system.outputs()['j_ion'].compression
+    assert 1 <= comp.rank <= 16 and comp.relative_error <= 0.01 and np.allclose(comp.coords, np.linspace(0, np.pi / 2, 91))
+    j = torch.from_numpy(outputs['j_ion']).cuda()
+    back = comp.reconstruct(comp.compress(j))
+    rel = float(torch.linalg.norm(back.log10() - j.log10()) / torch.linalg.norm(j.log10()))
+    assert rel <= 0.0101
+    again = PemV0System.load_from_file(tmp_path / 'compression' / f'{system.name}_compression.pkl')
+    c2 = again.outputs()['j_ion'].compression
+    assert c2.rank == comp.rank and torch.equal(c2.compress(j), comp.compress(j))
+
+    on_dev = drivers.generate_data(PemV0System(seed=11), 'test_set', num_samples=3000, device_resident=True)
+    x_dev, y_dev = on_dev['test_set']
+    assert y_dev['j_ion'].is_cuda and 'j_ion' + COORDS_STR_ID not in y_dev
+    # same seed, same design; the log10 / 10**x of the normalisation round trip run on the device here (ulp-level)
+    assert np.allclose(y_dev['V_cc'].cpu().numpy(), outputs['V_cc'], rtol=1e-12)
+    assert np.allclose(y_dev['j_ion'].cpu().numpy(), outputs['j_ion'], rtol=1e-11)
+
+
+@pytest.mark.gpu
+def test_fit_trains_a_surrogate_and_predict_switches_to_it():
+    from hallthrusterpem_amd.system import PemV0System
+    system = PemV0System(seed=2)
+    fixed = {k: v for k, v in dict(P_b=1e-5, V_a=300.0, T_e=2.0, Pstar=3e-5, P_T=2e-5, mdot_a=5e-6, a_1=0.01, c0=0.5,
+                                   c1=0.5, c4=1e20, c5=1e16, sigma_cex=55e-20).items()}
+    with pytest.raises(RuntimeError):
+        system.predict({'c2': np.zeros(3)}, normalized_inputs=False)
+    xt = system.sample_inputs(2000, normalize=False)
+    xt.update({k: np.full(2000, v) for k, v in fixed.items()})
+    yt = system.predict(xt, use_model='best', normalized_inputs=False)
+    hist = system.fit(targets=['V_cc', 'div_angle'], fixed=fixed, max_iter=8, max_tol=0.0, num_refine=500, test_set=(xt, yt))
+    assert len(hist) == 8 and hist[-1]['model_evals'] > hist[0]['model_evals']
+    errs = [h['test_error']['div_angle'] for h in hist]
+    assert errs[-1] < 0.5 * errs[0] and errs[-1] < 2e-2
+    pred = system.predict(xt, normalized_inputs=False)
+    assert set(pred) == {'V_cc', 'div_angle'} and pred['V_cc'].shape == (2000,)
+    assert np.linalg.norm(pred['V_cc'] - yt['V_cc']) / np.linalg.norm(yt['V_cc']) < 1e-2
+    cost_alloc, model_cost, overhead, evals = system.get_allocation()
+    assert evals.shape == (8,) and evals.sum() == hist[-1]['model_evals'] and overhead == 0.0
+    system.clear()
+    assert system.surrogate is None and system.train_history == []
