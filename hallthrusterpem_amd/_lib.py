@@ -41,6 +41,7 @@ SIGNATURES = {
     'pem_coupled_f64': (C.c_int, [_sz, _f8, _f8] + [_dp] * 15 + [_dp] * 7),
     'pem_coupled_mixed_dev': (C.c_int, [_sz, _f8, _f8] + [_dp] * 15 + [_dp] * 7 + [_dp]),
     'pem_coupled_loglik_f64_dev': (C.c_int, [_sz, _f8, _f8] + [_dp] * 15 + [C.c_int, C.c_int] + [_dp] * 4 + [_dp] * 5 + [_dp]),
+    'pem_coupled_latent_f64_dev': (C.c_int, [_sz, _f8, _f8] + [_dp] * 15 + [C.c_int, C.c_int, _dp, _dp] + [_dp] * 4 + [_dp]),
     'pem_loglik_marginal_f64_dev': (C.c_int, [_sz, C.c_int, C.c_int, _dp, _dp, _dp, _f8, _f8, _dp, _dp, _dp]),
     'pem_log_prior_f64_dev': (C.c_int, [_sz, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp]),
     'pem_jion_loglik_f64_dev': (C.c_int, [_sz, C.c_int, C.c_int] + [_dp] * 6 + [_dp]),

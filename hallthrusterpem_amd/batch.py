@@ -93,6 +93,28 @@ class CoupledBatch:
         _lib.check(rc)
         return out
 
+    def run_latent(self, compression, out=None, stream=None):
+        """Coupled evaluation + `compression.SVDCompression.compress(j_ion)` in one launch
+        (`pem_coupled_latent_f64_dev`): the latents are accumulated in the registers of the angle loop, the profile is
+        never stored.  Returns the (n, rank) latents; V_cc / div_angle / T_c / invalid are written as by `run`."""
+        import torch
+        from .compression import NORM_LINEAR
+        s = torch.cuda.current_stream(self.device) if stream is None else stream
+        c = compression
+        if c.norm == NORM_LINEAR:
+            raise NotImplementedError('the fused mode covers norm none / log10 (j_ion); use run() + compress()')
+        basis = c.basis.contiguous()
+        if basis.shape[0] != _lib.NANGLE:
+            raise ValueError('the compression map is not one of the 91-point profile')
+        if out is None:
+            out = torch.empty((self.n, c.rank), dtype=torch.float64, device=self.device)
+        p = lambda t: C.c_void_p(t.data_ptr())                                   # noqa: E731
+        rc = _lib.load().pem_coupled_latent_f64_dev(
+            self.n, constants.TORR_2_PA, self.radius, *self._in_ptrs, int(c.rank), int(c.norm), p(basis), p(out),
+            p(self.qoi[0]), p(self.qoi[1]), p(self.qoi[2]), p(self.invalid), C.c_void_p(s.cuda_stream))
+        _lib.check(rc)
+        return out
+
     def outputs(self) -> dict:
         out = {'V_cc': self.qoi[0], 'div_angle': self.qoi[1], 'T_c': self.qoi[2], 'invalid': self.invalid.bool()}
         if self.I_B0 is not None:

@@ -37,6 +37,7 @@
 #include <type_traits>
 
 #include "pem_common.h"
+#include "pem_math.h"
 #include "pem_hip.h"
 #include "pem_philox.h"
 
@@ -157,6 +158,10 @@ struct PlumeIO {
     const double *m_wgt, *m_y, *m_inv_std;
     double* loglik;
     int n_cond, n_ang;
+    // fused compression mode (JMODE 4): basis [91][rank] of the SVD map, the norm of the variable, latents [n][rank]
+    const double* basis;
+    double* latent;
+    int rank, log_norm;
 };
 
 struct CoupledIO {
@@ -269,6 +274,8 @@ __device__ __forceinline__ SampleIn<true> generate_sample(const McDesign& mc, lo
 //            2: mixed mode -- same fp64 arithmetic, profile rounded once to fp32 when it is staged
 //            3: fused likelihood -- the profile is staged in LDS only and reduced against measured current
 //               densities there (csrc/pem_likelihood.hip's formula); nothing but scalars leaves the chip
+//            4: fused compression -- latent = norm(j_ion) @ basis (csrc/pem_svd.hip's formula) accumulated from the
+//               registers of the angle loop: the profile is neither staged nor stored
 // LDS map (doubles): shared by the workgroup: simpson[96][2] | dpoly[32*12];  per wave: params[NROWS][64] |
 // tile[S*91] | 2 (sink).  The Simpson table is padded with zero weights to L*CH <= 96 entries so the angle loop
 // needs no branch.  The den/num partial sums of a round reuse the rows of `params` that the round has consumed.
@@ -276,6 +283,7 @@ __device__ __forceinline__ SampleIn<true> generate_sample(const McDesign& mc, lo
 constexpr int NPARAM = 9;   // X1 X2 jcex | r0 G E (beam 1) | r0 G E (beam 2)
 constexpr int NSIMP = 96;   // >= L*CH for L in {2, 4, 8}
 constexpr int WPB = 4;      // waves per workgroup (they share the two tables and nothing else)
+constexpr int LAT_RT = 8;   // latent columns of the fused compression mode (rank <= 8; j_ion needs 5-6 at tol 0.01)
 template <int L>
 constexpr int param_rows() { return 2 * L > NPARAM ? 2 * L : NPARAM; }   // rows 2c, 2c+1 are reused for the Simpson partials
 constexpr int TABLE_DOUBLES = 2 * NSIMP + PEM_NDI * PEM_NDC;
@@ -312,6 +320,7 @@ __device__ __forceinline__ void stream_store(f64x2 v, f64x2* dst) {
 
 // LDS views of one wave
 struct WaveLds {
+    const double* basis;     // fused compression: [96][LAT_RT] zero-padded basis rows, then colsum[LAT_RT]; or nullptr
     const double* meas;      // fused likelihood: [n_cond*n_ang] records {weight, y, inv_std, k (integer bits)}, or nullptr
     const double2* simpson;  // [96] {cden, cnum}
     const double* poly;      // [32*12]
@@ -329,7 +338,8 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
     constexpr int S = WAVE / L;             // samples per round
     constexpr int CH = (NANG + L - 1) / L;  // angles per lane
     constexpr int TILE = S * NANG;          // profile values per round tile
-    constexpr bool WRITE_J = JMODE != 0;
+    constexpr bool WRITE_J = JMODE != 0 && JMODE != 4;
+    constexpr bool LATENT = JMODE == 4;
     using JT = typename std::conditional<JMODE == 2, float, double>::type;   // element type of the stored profile
     constexpr int PER16 = 16 / (int)sizeof(JT);                              // values per 16-byte piece
     constexpr int PAIRS = TILE / PER16;     // 16-byte pieces of a full round tile (TILE divides evenly)
@@ -410,14 +420,50 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
         }
         const double q1 = r01 * r01, q2 = r02 * r02;
         double den = 0.0, num = 0.0, lo = __builtin_inf();
+        double lat[LATENT ? LAT_RT : 1];
+        if constexpr (LATENT) {
+#pragma unroll
+            for (int r = 0; r < LAT_RT; ++r) lat[r] = 0.0;
+        }
         // The weight reads are issued PF iterations ahead IN SOURCE ORDER: the tile stores in between are
         // LDS stores the compiler must assume may alias the table, so it cannot hoist the reads itself.
         constexpr int PF = 6;
         double2 wq[CH];
+        if constexpr (LATENT) {
+            // a rolled loop: 23 inlined log10 evaluations in one basic block cost 512 registers and scratch
+#ifndef PEM_LATENT_UNROLL
+#define PEM_LATENT_UNROLL 4
+#endif
+#pragma unroll PEM_LATENT_UNROLL
+            for (int j = 0; j < CH; ++j) {
+                const double2 w = my_w[j];
+                const double f = X1 + X2;
+                const double ji = f + jcex;
+                const bool in_range = k0 + j < NANG;
+                lo = fmin(lo, in_range ? f : __builtin_inf());
+                den = fma(w.x, f, den);
+                num = fma(w.y, f, num);
+                // norm(j_ion[k]) times basis row k, straight from the registers; past 90 degrees the basis rows are
+                // zero, but 0 * log10(0) is not
+                double lj = io.log_norm ? pem::pem_log10(ji) : ji;
+                lj = in_range ? lj : 0.0;
+                const f64x2* brow = reinterpret_cast<const f64x2*>(m.basis + (k0 + j) * LAT_RT);
+#pragma unroll
+                for (int r = 0; r < LAT_RT; r += 2) {
+                    const f64x2 b = brow[r >> 1];
+                    lat[r] = fma(lj, b.x, lat[r]);
+                    lat[r + 1] = fma(lj, b.y, lat[r + 1]);
+                }
+                X1 *= rr1;
+                rr1 *= q1;
+                X2 *= rr2;
+                rr2 *= q2;
+            }
+        }
 #pragma unroll
         for (int j = 0; WRITE_J && j < PF && j < CH; ++j) wq[j] = my_w[j];
 #pragma unroll
-        for (int j = 0; j < CH; ++j) {
+        for (int j = 0; !LATENT && j < CH; ++j) {
             if constexpr (!WRITE_J) wq[j] = my_w[j];   // no tile stores in between: the compiler schedules the reads
             else if (j + PF < CH) wq[j + PF] = my_w[j + PF];
             const double f = X1 + X2;     // j_beam + j_scat
@@ -447,6 +493,19 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
         for (int sh = S; sh < WAVE; sh <<= 1) bad |= bad >> sh;   // fold the L chunk lanes of a sample onto bit s
         bad = (bad | (a1_nonpos >> (round * S))) & ((S == 64) ? ~0ull : ((1ull << S) - 1));
         inv_mask |= bad << (round * S);
+        if constexpr (LATENT) {
+            const long long smp_g = t * WAVE + smp;
+            const bool is_bad = (bad >> s) & 1;
+            const double fill = io.log_norm ? -20.0 : 1e-20;   // norm(1e-20): the profile of an invalid sample (plume.py:106)
+#pragma unroll
+            for (int r = 0; r < LAT_RT; ++r) {
+                double v = lat[r];
+#pragma unroll
+                for (int sh = S; sh < WAVE; sh <<= 1) v += __shfl_xor(v, sh);   // the L chunk lanes of sample s
+                if (is_bad) v = fill * m.basis[96 * LAT_RT + r];
+                if (c == 0 && r < io.rank && (FULL || smp_g < io.n)) io.latent[smp_g * io.rank + r] = v;
+            }
+        }
         if constexpr (WRITE_J) {
             if ((bad >> s) & 1) {  // plume.py:106: the whole profile of an invalid sample becomes 1e-20 (rare)
                 for (int j = 0; j < CH; ++j)
@@ -557,6 +616,21 @@ __global__ __launch_bounds__(WAVE * WPB) void plume_r1_kernel(PlumeIO io, Couple
     m.poly = tab_poly;
     m.params = lds + TABLE_DOUBLES + wave * wave_lds_doubles<L, JMODE>();   // [rows][64], private to this wave
     m.tile = m.params + param_rows<L>() * WAVE;                               // [S*91] + sink
+    m.basis = nullptr;
+    if constexpr (JMODE == 4) {   // zero-padded basis [96][LAT_RT] + column sums, behind the per-wave regions
+        double* bas = lds + TABLE_DOUBLES + WPB * wave_lds_doubles<L, JMODE>();
+        for (int i = tid; i < 96 * LAT_RT; i += WAVE * WPB) {
+            const int k = i / LAT_RT, r = i - k * LAT_RT;
+            bas[i] = (k < NANG && r < io.rank) ? io.basis[k * io.rank + r] : 0.0;
+        }
+        if (tid < LAT_RT) {
+            double sum = 0.0;
+            if (tid < io.rank)
+                for (int k = 0; k < NANG; ++k) sum += io.basis[k * io.rank + tid];
+            bas[96 * LAT_RT + tid] = sum;
+        }
+        m.basis = bas;
+    }
     m.meas = nullptr;
     if constexpr (JMODE == 3) {   // measurement tables behind the per-wave regions (vmcnt is in order: never global)
         double* meas = lds + TABLE_DOUBLES + WPB * wave_lds_doubles<L, JMODE>();
@@ -813,6 +887,7 @@ template <int L, bool COUPLED, int JMODE, bool MC = false>
 int launch_r1(const PlumeIO& io, const CoupledIO& cio, hipStream_t st, const McDesign& mc = McDesign{}) {
     size_t lds = (size_t)fast_lds_doubles<L, JMODE>() * 8;
     if (JMODE == 3) lds += (size_t)io.n_cond * (io.n_ang | 1) * 32;
+    if (JMODE == 4) lds += (size_t)(96 + 1) * LAT_RT * 8;
     const long long ntiles = (io.n + WAVE - 1) / WAVE;
     unsigned grid = 0;
     if (int rc = fast_grid(lds, ntiles, &grid)) return rc;
@@ -1057,6 +1132,28 @@ int pem_coupled_loglik_f64_dev(size_t n, double torr2pa, double radius, const do
                kidx, weight, y, inv_std, loglik, n_cond, n_ang};
     CoupledIO cio{V_a, T_e, V_vac, Pstar, P_T, mdot_a, a_1, V_cc, nullptr, nullptr};
     return launch_r1<4, true, 3>(io, cio, static_cast<hipStream_t>(stream));
+}
+
+// ---- coupled + SVD compression fused: latent = norm(j_ion) @ basis without the profile ever existing in memory ------
+int pem_coupled_latent_f64_dev(size_t n, double torr2pa, double radius, const double* P_b, const double* V_a,
+                               const double* T_e, const double* V_vac, const double* Pstar, const double* P_T,
+                               const double* mdot_a, const double* a_1, const double* c0, const double* c1, const double* c2,
+                               const double* c3, const double* c4, const double* c5, const double* sigma_cex, int rank,
+                               int norm, const double* basis, double* latent, double* V_cc, double* div_angle, double* T_c,
+                               uint8_t* invalid, pem_stream_t stream) {
+    if (rank < 1 || rank > PEM_FUSED_LATENT_MAX_RANK)
+        return fail(PEM_ERR_INVALID_ARG, "pem_coupled_latent: 1 <= rank <= %d", PEM_FUSED_LATENT_MAX_RANK);
+    if (norm != PEM_NORM_NONE && norm != PEM_NORM_LOG10)
+        return fail(PEM_ERR_INVALID_ARG, "pem_coupled_latent: norm must be PEM_NORM_NONE or PEM_NORM_LOG10");
+    if (n == 0) return PEM_OK;
+    if (!P_b || !V_a || !T_e || !V_vac || !Pstar || !P_T || !mdot_a || !a_1 || !c0 || !c1 || !c2 || !c3 || !c4 || !c5 ||
+        !sigma_cex || !basis || !latent || !V_cc || !div_angle || !T_c)
+        return fail(PEM_ERR_INVALID_ARG, "pem_coupled_latent: NULL array");
+    if (int rc = check_device()) return rc;
+    PlumeIO io{(long long)n, torr2pa, radius, P_b, c0, c1, c2, c3, c4, c5, sigma_cex, nullptr, nullptr, nullptr, div_angle, T_c, invalid, nullptr,
+               nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, basis, latent, rank, norm == PEM_NORM_LOG10 ? 1 : 0};
+    CoupledIO cio{V_a, T_e, V_vac, Pstar, P_T, mdot_a, a_1, V_cc, nullptr, nullptr};
+    return launch_r1<4, true, 4>(io, cio, static_cast<hipStream_t>(stream));
 }
 
 // ---- coupled, mixed precision: fp64 arithmetic, the 91-point profile stored as fp32 -----------------

@@ -187,6 +187,19 @@ int pem_coupled_loglik_f64_dev(size_t n, double torr2pa, double radius, const do
                                const double* weight, const double* y, const double* inv_std, double* V_cc,
                                double* div_angle, double* T_c, double* loglik, uint8_t* invalid, pem_stream_t stream);
 
+/* pem_coupled_f64_dev + pem_svd_compress_f64_dev in one launch: latent[i][r] = sum_k norm(j_ion[i][k]) basis[k][r]
+ * accumulated in the registers of the angle loop -- the profile is neither stored nor staged (120 + 24 + 8 rank bytes
+ * per evaluation).  norm: PEM_NORM_NONE or PEM_NORM_LOG10; basis: [91][rank] device array, rank <=
+ * PEM_FUSED_LATENT_MAX_RANK; latent: [n][rank].  An invalid sample gets the latents of its 1e-20 profile
+ * (plume.py:106), as the two-launch pipeline gives.                                                               */
+#define PEM_FUSED_LATENT_MAX_RANK 8
+int pem_coupled_latent_f64_dev(size_t n, double torr2pa, double radius, const double* P_b, const double* V_a,
+                               const double* T_e, const double* V_vac, const double* Pstar, const double* P_T,
+                               const double* mdot_a, const double* a_1, const double* c0, const double* c1,
+                               const double* c2, const double* c3, const double* c4, const double* c5,
+                               const double* sigma_cex, int rank, int norm, const double* basis, double* latent,
+                               double* V_cc, double* div_angle, double* T_c, uint8_t* invalid, pem_stream_t stream);
+
 /* Marginal likelihood over nuisance draws and the prior of the calibration parameters (mcmc.py:100-121; unpinned).
  * loglik: [n_chains][n_draws][n_cond] per-sample sums (pem_jion_loglik / pem_coupled_loglik output).
  * out[k] = logsumexp_m( sum_e loglik[k][m][e] + sum_e -0.5 ((discharge_current - I_d[k][m][e]) / discharge_sigma)^2 ),

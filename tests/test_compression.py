@@ -101,3 +101,40 @@ def test_fused_log10_and_exp10_norms_elementwise():
     assert np.max(np.abs(got[fin] - want[fin]) / want[fin]) <= 4.5e-16
     assert got[0, 0] == 1.0 and got[0, 1] == 10.0 and got[0, 2] == 100.0 and got[0, 12] == np.inf
     assert got[0, 11] == pytest.approx(1e-320, rel=1e-3) and got[0, 13] == 0.0      # denormal result, underflow
+
+
+@pytest.mark.parametrize('norm', ['log10', 'none'])
+@pytest.mark.parametrize('n', [1, 777, 100_003])
+def test_fused_coupled_compression_matches_two_launch_pipeline(n, norm):
+    """pem_coupled_latent_f64_dev == pem_coupled_f64_dev followed by pem_svd_compress_f64_dev, invalid samples included."""
+    import torch
+    from hallthrusterpem_amd.batch import CoupledBatch
+    from hallthrusterpem_amd.compression import SVDCompression
+    from hallthrusterpem_amd.sampling import Design
+    rng = np.random.default_rng(3)
+    rank = 6
+    basis = np.linalg.qr(rng.standard_normal((91, rank)))[0]
+    c = SVDCompression(norm=norm, rank=rank)
+    c.basis = torch.from_numpy(np.ascontiguousarray(basis)).cuda()
+    ref = CoupledBatch(n, profile=True, thruster_qoi=False)
+    Design(seed=31).fill(ref.inputs)
+    if n > 10:
+        ref.inputs[10, 5:9], ref.inputs[11, 5:9] = 0.0, -1.0          # alpha1 = c3 <= 0: invalid, profile 1e-20
+    ref.run()
+    want = c.compress(ref.j_ion)
+    fused = CoupledBatch(n, profile=False, thruster_qoi=False)
+    fused.inputs.copy_(ref.inputs)
+    got = fused.run_latent(c)
+    torch.cuda.synchronize()
+    assert got.shape == (n, rank)
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 1e-12 * max(1.0, scale)
+    # same formulas; the rolled angle loop of the fused mode lets hipcc contract mul+add pairs differently (ulp level)
+    assert float(((ref.qoi - fused.qoi).abs() / ref.qoi.abs().clamp_min(1e-300)).max()) < 1e-13
+    assert torch.equal(ref.invalid, fused.invalid)
+    if n > 10:
+        assert ref.invalid[5:9].all()
+    with pytest.raises(Exception):
+        big = SVDCompression(norm=norm, rank=9)
+        big.basis = torch.zeros((91, 9), dtype=torch.float64, device='cuda')
+        fused.run_latent(big)

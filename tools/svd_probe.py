@@ -24,3 +24,17 @@ for norm in ('log10', 'none'):
     ms_c = t(lambda: c.compress(j)); ms_r = t(lambda: c.reconstruct(z))
     by = n * (91 + c.rank) * 8
     print(f'norm={norm:5s} rank={c.rank}: compress {ms_c*1e3:7.1f} us {by/ms_c/1e6:6.0f} GB/s | reconstruct {ms_r*1e3:7.1f} us {by/ms_r/1e6:6.0f} GB/s  (incl. output alloc)')
+
+# fused: coupled evaluation + compression in one launch (the profile never exists in memory)
+from hallthrusterpem_amd.batch import CoupledBatch
+from hallthrusterpem_amd.sampling import Design
+c = SVDCompression(norm='log10', reconstruction_tol=0.01).fit(j[:50_000])
+two = CoupledBatch(n, profile=True, thruster_qoi=False)
+Design(seed=2).fill(two.inputs)
+fused = CoupledBatch(n, profile=False, thruster_qoi=False)
+fused.inputs.copy_(two.inputs)
+out = torch.empty((n, c.rank), dtype=torch.float64, device='cuda')
+ms2 = t(lambda: (two.run(), c.compress(two.j_ion)))
+ms1 = t(lambda: fused.run_latent(c, out=out))
+print(f'coupled -> compress(log10, rank {c.rank}): two launches {ms2*1e3:.1f} us; fused pem_coupled_latent {ms1*1e3:.1f} us '
+      f'({n/ms1/1e6:.2f} G evals/s)')
