@@ -10,3 +10,9 @@ The arithmetic runs in hand-written HIP kernels for gfx950 behind the C ABI of i
 __version__ = '0.1.0'
 
 from . import constants  # noqa: F401
+
+
+def set_device(index: int):
+    """Select this process's GPU for every thread (see `_lib.set_device`)."""
+    from . import _lib
+    _lib.set_device(index)

@@ -118,6 +118,17 @@ def device_count() -> int:
     return int(load().pem_device_count())
 
 
+def set_device(index: int):
+    """Select the GPU of this process (one process per GPU): `pem_init(index)` makes it the device of the host-pointer
+    entry points for every thread of the process, and torch's current device is set to match."""
+    check(load().pem_init(int(index)))
+    try:
+        import torch
+        torch.cuda.set_device(int(index))
+    except ImportError:
+        pass
+
+
 def require_device():
     if device_count() < 1:
         raise PemHipError(PEM_ERR_NO_DEVICE, 'no HIP device visible; hallthrusterpem_amd has no CPU path')

@@ -33,6 +33,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <type_traits>
 
@@ -856,6 +857,16 @@ __global__ __launch_bounds__(BLOCK) void thruster_filter_kernel(long long n, int
 // host side
 // ---------------------------------------------------------------------------------------------
 int g_lanes = 4;
+std::atomic<int> g_device{-1};   // process default of the host-pointer entry points (pem_init); -1: the calling thread's
+
+// Host-pointer entry points run on the device given to pem_init, whichever thread calls them: a new thread's current
+// HIP device is 0, which is the wrong card for the worker threads of a one-process-per-GPU rank (gen_data.py:448-456
+// evaluates models on Thread pools).
+int use_default_device() {
+    const int d = g_device.load(std::memory_order_relaxed);
+    if (d >= 0) HIP_TRY(hipSetDevice(d));
+    return PEM_OK;
+}
 double g_angle_grid[NANG];
 std::once_flag g_grid_once;
 using pem::check_device;
@@ -980,6 +991,7 @@ int pem_device_count(void) {
 int pem_init(int device) {
     if (int rc = check_device()) return rc;
     HIP_TRY(hipSetDevice(device));
+    g_device.store(device, std::memory_order_relaxed);
     return PEM_OK;
 }
 
@@ -1211,6 +1223,7 @@ int pem_cathode_f64(size_t n, const double* P_b, const double* V_a, const double
     if (n == 0) return PEM_OK;
     if (!P_b || !V_a || !T_e || !V_vac || !Pstar || !P_T || !V_cc) return fail(PEM_ERR_INVALID_ARG, "pem_cathode: NULL array");
     if (int rc = check_device()) return rc;
+    if (int rc = use_default_device()) return rc;
     std::lock_guard<std::mutex> lock(g_ws.mu);
     const size_t chunk = n < (size_t(1) << 24) ? n : (size_t(1) << 24);
     if (int rc = g_ws.reserve(7 * padded(chunk * 8))) return rc;
@@ -1234,6 +1247,7 @@ int pem_thruster_f64(size_t n, const double* V_a, const double* V_cc, const doub
     if (n == 0) return PEM_OK;
     if (!V_a || !V_cc || !mdot_a || !a_1) return fail(PEM_ERR_INVALID_ARG, "pem_thruster: NULL input array");
     if (int rc = check_device()) return rc;
+    if (int rc = use_default_device()) return rc;
     std::lock_guard<std::mutex> lock(g_ws.mu);
     const size_t chunk = n < (size_t(1) << 24) ? n : (size_t(1) << 24);
     if (int rc = g_ws.reserve(12 * padded(chunk * 8))) return rc;
@@ -1266,6 +1280,7 @@ int pem_plume_f64(size_t n, int n_radii, const double* radii, double torr2pa, co
         return fail(PEM_ERR_INVALID_ARG, "pem_plume: NULL array");
     if ((T == nullptr) != (T_c == nullptr)) return fail(PEM_ERR_INVALID_ARG, "pem_plume: T and T_c go together");
     if (int rc = check_device()) return rc;
+    if (int rc = use_default_device()) return rc;
     std::lock_guard<std::mutex> lock(g_ws.mu);
     const size_t R = (size_t)n_radii;
     // bound the profile chunk to ~256 MiB of device memory
@@ -1310,6 +1325,7 @@ int pem_coupled_f64(size_t n, double torr2pa, double radius, const double* P_b, 
         if (!p) return fail(PEM_ERR_INVALID_ARG, "pem_coupled: NULL input array");
     if (!V_cc || !div_angle || !T_c) return fail(PEM_ERR_INVALID_ARG, "pem_coupled: NULL output array");
     if (int rc = check_device()) return rc;
+    if (int rc = use_default_device()) return rc;
     std::lock_guard<std::mutex> lock(g_ws.mu);
     size_t chunk = (size_t(1) << 28) / (NANG * 8);
     if (chunk > n) chunk = n;

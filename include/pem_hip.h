@@ -57,7 +57,9 @@ typedef void* pem_stream_t; /* hipStream_t */
 const char* pem_version(void);
 const char* pem_last_error(void);
 int pem_device_count(void);                 /* number of HIP devices, 0 if none / no driver        */
-int pem_init(int device);                   /* hipSetDevice(device) + upload the constant tables   */
+/* hipSetDevice(device) and make it the process default of the host-pointer entry points, whichever thread calls them
+ * (without pem_init they run on the calling thread's current device).  The *_dev entry points follow their stream. */
+int pem_init(int device);
 int pem_synchronize(pem_stream_t stream);   /* hipStreamSynchronize                                */
 /* Tuning knob of the plume/coupled kernels: lanes that share one sample (2, 4 or 8).
  * 0 restores the default.  Returns the value in effect. */

@@ -368,3 +368,35 @@ def test_large_batch_index_arithmetic(pem):
     torch.cuda.synchronize()
     assert torch.equal(big.qoi[:, idx], small.qoi)
     assert bool(torch.isfinite(big.qoi).all())
+
+
+def test_host_entry_points_from_a_thread_pool(pem, oc):
+    """SURVEY section 8b, threading: the reference evaluates models on Thread pools (gen_data.py:448-456); ctypes
+    releases the GIL, so the host-pointer entry points really run concurrently.  Every call must return exactly what
+    it returns alone, on the process's device (new threads start on HIP device 0; pem_init pins the choice)."""
+    from concurrent.futures import ThreadPoolExecutor
+    import hallthrusterpem_amd
+    from hallthrusterpem_amd.models import cathode_coupling, current_density
+    hallthrusterpem_amd.set_device(0)
+    jobs = []
+    for seed in range(24):
+        rng = np.random.default_rng(seed)
+        n = int(rng.integers(1, 5000))
+        if seed % 2:
+            jobs.append((cathode_coupling, {'P_b': 10.0 ** rng.uniform(-8, -4, n), 'V_a': rng.uniform(200, 400, n),
+                                            'T_e': rng.uniform(1, 5, n), 'V_vac': rng.uniform(0, 60, n),
+                                            'Pstar': rng.uniform(1e-5, 1e-4, n), 'P_T': rng.uniform(1e-5, 1e-4, n)}))
+        else:
+            jobs.append((current_density, {'P_b': 10.0 ** rng.uniform(-8, -4, n), 'c0': rng.uniform(0, 1, n),
+                                           'c1': rng.uniform(0.1, 0.9, n), 'c2': rng.uniform(-15, 15, n),
+                                           'c3': rng.uniform(0.2, 1.57, n), 'c4': 10.0 ** rng.uniform(18, 22, n),
+                                           'c5': 10.0 ** rng.uniform(14, 18, n), 'sigma_cex': rng.uniform(51e-20, 58e-20, n),
+                                           'I_B0': rng.uniform(2, 8, n), 'T': rng.uniform(0.05, 0.1, n)}))
+    alone = [f(x) for f, x in jobs]
+    with ThreadPoolExecutor(max_workers=8) as pool:
+        for _ in range(3):
+            together = list(pool.map(lambda job: job[0](job[1]), jobs))
+            for a, b in zip(alone, together):
+                for k in a:
+                    if k != 'j_ion_coords':
+                        assert np.array_equal(a[k], b[k], equal_nan=True), k
