@@ -961,6 +961,75 @@ struct Carver {
 };
 size_t padded(size_t bytes) { return (bytes + 255) & ~size_t(255); }
 
+// Host <-> device movement of one chunk of a host-pointer entry point.  A chunk whose whole workspace footprint fits
+// the pinned staging buffer is moved with ONE host-to-device and ONE device-to-host copy through a pinned mirror of the
+// workspace layout (inputs are carved first, outputs after them, so each side is one contiguous range): a call with
+// 15 input and 6 output arrays otherwise pays ~20 pageable-copy latencies (coupled, n = 1: 186 us -> see
+// tools/latency_probe.py).  Larger chunks copy array by array, where bandwidth is what matters.
+constexpr size_t STAGE_BYTES = size_t(2) << 20;
+struct Stage {
+    unsigned char* pin = nullptr;
+    bool tried = false;
+    unsigned char* get() {
+        if (!tried) {
+            tried = true;
+            void* p = nullptr;
+            if (hipHostMalloc(&p, STAGE_BYTES, hipHostMallocPortable) == hipSuccess) pin = static_cast<unsigned char*>(p);
+            else (void)hipGetLastError();
+        }
+        return pin;
+    }
+} g_stage;   // guarded by g_ws.mu
+
+struct Mover {
+    unsigned char* ws;
+    unsigned char* pin;   // nullptr: array-by-array copies
+    size_t in_lo = ~size_t(0), in_hi = 0, out_lo = ~size_t(0), out_hi = 0;
+    struct Out {
+        void* host;
+        size_t off, bytes;
+    } outs[8];
+    int nout = 0;
+    Mover(void* workspace, size_t footprint)
+        : ws(static_cast<unsigned char*>(workspace)), pin(footprint <= STAGE_BYTES ? g_stage.get() : nullptr) {}
+    int in(const void* host, void* dev, size_t bytes) {
+        if (!pin) {
+            HIP_TRY(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, nullptr));
+            return PEM_OK;
+        }
+        const size_t off = static_cast<unsigned char*>(dev) - ws;
+        memcpy(pin + off, host, bytes);
+        if (off < in_lo) in_lo = off;
+        if (off + bytes > in_hi) in_hi = off + bytes;
+        return PEM_OK;
+    }
+    int flush_in() {
+        if (pin && in_hi > in_lo) HIP_TRY(hipMemcpyAsync(ws + in_lo, pin + in_lo, in_hi - in_lo, hipMemcpyHostToDevice, nullptr));
+        return PEM_OK;
+    }
+    int out(void* host, const void* dev, size_t bytes) {
+        if (!pin || nout == 8) {
+            HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, nullptr));
+            return PEM_OK;
+        }
+        const size_t off = static_cast<const unsigned char*>(dev) - ws;
+        outs[nout++] = Out{host, off, bytes};
+        if (off < out_lo) out_lo = off;
+        if (off + bytes > out_hi) out_hi = off + bytes;
+        return PEM_OK;
+    }
+    int finish() {
+        if (pin && out_hi > out_lo) HIP_TRY(hipMemcpyAsync(pin + out_lo, ws + out_lo, out_hi - out_lo, hipMemcpyDeviceToHost, nullptr));
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        for (int i = 0; i < nout; ++i) memcpy(outs[i].host, pin + outs[i].off, outs[i].bytes);
+        return PEM_OK;
+    }
+};
+#define PEM_TRY(expr)              \
+    do {                           \
+        if (int rc_ = (expr)) return rc_; \
+    } while (0)
+
 }  // namespace
 
 namespace pem {
@@ -1233,10 +1302,12 @@ int pem_cathode_f64(size_t n, const double* P_b, const double* V_a, const double
         Carver cv(g_ws.buf);
         double* d[7];
         for (auto& p : d) p = cv.take<double>(chunk);
-        for (int i = 0; i < 6; ++i) HIP_TRY(hipMemcpyAsync(d[i], in[i] + off, m * 8, hipMemcpyHostToDevice, nullptr));
+        Mover mv(g_ws.buf, cv.off);
+        for (int i = 0; i < 6; ++i) PEM_TRY(mv.in(in[i] + off, d[i], m * 8));
+        PEM_TRY(mv.flush_in());
         if (int rc = pem_cathode_f64_dev(m, d[0], d[1], d[2], d[3], d[4], d[5], torr2pa, d[6], nullptr)) return rc;
-        HIP_TRY(hipMemcpyAsync(V_cc + off, d[6], m * 8, hipMemcpyDeviceToHost, nullptr));
-        HIP_TRY(hipStreamSynchronize(nullptr));
+        PEM_TRY(mv.out(V_cc + off, d[6], m * 8));
+        PEM_TRY(mv.finish());
     }
     return PEM_OK;
 }
@@ -1259,13 +1330,15 @@ int pem_thruster_f64(size_t n, const double* V_a, const double* V_cc, const doub
         double *di[4], *dout[8];
         for (auto& p : di) p = cv.take<double>(chunk);
         for (int i = 0; i < 8; ++i) dout[i] = out[i] ? cv.take<double>(chunk) : nullptr;
-        for (int i = 0; i < 4; ++i) HIP_TRY(hipMemcpyAsync(di[i], in[i] + off, m * 8, hipMemcpyHostToDevice, nullptr));
+        Mover mv(g_ws.buf, cv.off);
+        for (int i = 0; i < 4; ++i) PEM_TRY(mv.in(in[i] + off, di[i], m * 8));
+        PEM_TRY(mv.flush_in());
         if (int rc = pem_thruster_f64_dev(m, di[0], di[1], di[2], di[3], dout[0], dout[1], dout[2], dout[3], dout[4],
                                           dout[5], dout[6], dout[7], nullptr))
             return rc;
         for (int i = 0; i < 8; ++i)
-            if (out[i]) HIP_TRY(hipMemcpyAsync(out[i] + off, dout[i], m * 8, hipMemcpyDeviceToHost, nullptr));
-        HIP_TRY(hipStreamSynchronize(nullptr));
+            if (out[i]) PEM_TRY(mv.out(out[i] + off, dout[i], m * 8));
+        PEM_TRY(mv.finish());
     }
     return PEM_OK;
 }
@@ -1300,16 +1373,18 @@ int pem_plume_f64(size_t n, int n_radii, const double* radii, double torr2pa, co
         double* ddiv = cv.take<double>(chunk * R);
         double* dtc = cv.take<double>(chunk * R);
         uint8_t* dinv = cv.take<uint8_t>(chunk);
+        Mover mv(g_ws.buf, cv.off);
         for (int i = 0; i < 10; ++i)
-            if (in[i]) HIP_TRY(hipMemcpyAsync(d[i], in[i] + off, m * 8, hipMemcpyHostToDevice, nullptr));
+            if (in[i]) PEM_TRY(mv.in(in[i] + off, d[i], m * 8));
+        PEM_TRY(mv.flush_in());
         if (int rc = pem_plume_f64_dev(m, n_radii, radii, torr2pa, d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8],
                                        T ? d[9] : nullptr, dj, ddiv, T ? dtc : nullptr, invalid ? dinv : nullptr, nullptr))
             return rc;
-        HIP_TRY(hipMemcpyAsync(j_ion + off * NANG * R, dj, m * NANG * R * 8, hipMemcpyDeviceToHost, nullptr));
-        HIP_TRY(hipMemcpyAsync(div_angle + off * R, ddiv, m * R * 8, hipMemcpyDeviceToHost, nullptr));
-        if (T) HIP_TRY(hipMemcpyAsync(T_c + off * R, dtc, m * R * 8, hipMemcpyDeviceToHost, nullptr));
-        if (invalid) HIP_TRY(hipMemcpyAsync(invalid + off, dinv, m, hipMemcpyDeviceToHost, nullptr));
-        HIP_TRY(hipStreamSynchronize(nullptr));
+        PEM_TRY(mv.out(j_ion + off * NANG * R, dj, m * NANG * R * 8));
+        PEM_TRY(mv.out(div_angle + off * R, ddiv, m * R * 8));
+        if (T) PEM_TRY(mv.out(T_c + off * R, dtc, m * R * 8));
+        if (invalid) PEM_TRY(mv.out(invalid + off, dinv, m));
+        PEM_TRY(mv.finish());
     }
     return PEM_OK;
 }
@@ -1342,21 +1417,23 @@ int pem_coupled_f64(size_t n, double torr2pa, double radius, const double* P_b, 
         double* dT = cv.take<double>(chunk);
         double* ddiv = cv.take<double>(chunk);
         double* dtc = cv.take<double>(chunk);
-        double* dj = cv.take<double>(chunk * NANG);
         uint8_t* dinv = cv.take<uint8_t>(chunk);
-        for (int i = 0; i < 15; ++i) HIP_TRY(hipMemcpyAsync(d[i], in[i] + off, m * 8, hipMemcpyHostToDevice, nullptr));
+        double* dj = cv.take<double>(chunk * NANG);   // last: without a profile the staged copy-back stops before it
+        Mover mv(g_ws.buf, cv.off);
+        for (int i = 0; i < 15; ++i) PEM_TRY(mv.in(in[i] + off, d[i], m * 8));
+        PEM_TRY(mv.flush_in());
         if (int rc = pem_coupled_f64_dev(m, torr2pa, radius, d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], d[9],
                                          d[10], d[11], d[12], d[13], d[14], dvcc, I_B0 ? dib0 : nullptr, T ? dT : nullptr,
                                          j_ion ? dj : nullptr, ddiv, dtc, invalid ? dinv : nullptr, nullptr))
             return rc;
-        HIP_TRY(hipMemcpyAsync(V_cc + off, dvcc, m * 8, hipMemcpyDeviceToHost, nullptr));
-        if (I_B0) HIP_TRY(hipMemcpyAsync(I_B0 + off, dib0, m * 8, hipMemcpyDeviceToHost, nullptr));
-        if (T) HIP_TRY(hipMemcpyAsync(T + off, dT, m * 8, hipMemcpyDeviceToHost, nullptr));
-        if (j_ion) HIP_TRY(hipMemcpyAsync(j_ion + off * NANG, dj, m * NANG * 8, hipMemcpyDeviceToHost, nullptr));
-        HIP_TRY(hipMemcpyAsync(div_angle + off, ddiv, m * 8, hipMemcpyDeviceToHost, nullptr));
-        HIP_TRY(hipMemcpyAsync(T_c + off, dtc, m * 8, hipMemcpyDeviceToHost, nullptr));
-        if (invalid) HIP_TRY(hipMemcpyAsync(invalid + off, dinv, m, hipMemcpyDeviceToHost, nullptr));
-        HIP_TRY(hipStreamSynchronize(nullptr));
+        PEM_TRY(mv.out(V_cc + off, dvcc, m * 8));
+        if (I_B0) PEM_TRY(mv.out(I_B0 + off, dib0, m * 8));
+        if (T) PEM_TRY(mv.out(T + off, dT, m * 8));
+        if (j_ion) PEM_TRY(mv.out(j_ion + off * NANG, dj, m * NANG * 8));
+        PEM_TRY(mv.out(div_angle + off, ddiv, m * 8));
+        PEM_TRY(mv.out(T_c + off, dtc, m * 8));
+        if (invalid) PEM_TRY(mv.out(invalid + off, dinv, m));
+        PEM_TRY(mv.finish());
     }
     return PEM_OK;
 }
