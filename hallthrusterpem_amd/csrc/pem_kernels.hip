@@ -964,8 +964,9 @@ size_t padded(size_t bytes) { return (bytes + 255) & ~size_t(255); }
 // Host <-> device movement of one chunk of a host-pointer entry point.  A chunk whose whole workspace footprint fits
 // the pinned staging buffer is moved with ONE host-to-device and ONE device-to-host copy through a pinned mirror of the
 // workspace layout (inputs are carved first, outputs after them, so each side is one contiguous range): a call with
-// 15 input and 6 output arrays otherwise pays ~20 pageable-copy latencies (coupled, n = 1: 186 us -> see
-// tools/latency_probe.py).  Larger chunks copy array by array, where bandwidth is what matters.
+// 15 input and 6 output arrays otherwise pays ~20 pageable-copy latencies (coupled, n = 1: 186 -> 61 us per call,
+// tools/latency_probe.py).  The two sides decide separately: inputs are staged when they fit, outputs when the whole
+// footprint does; what does not fit is copied array by array, where bandwidth is what matters.
 constexpr size_t STAGE_BYTES = size_t(2) << 20;
 struct Stage {
     unsigned char* pin = nullptr;
@@ -983,15 +984,19 @@ struct Stage {
 
 struct Mover {
     unsigned char* ws;
-    unsigned char* pin;   // nullptr: array-by-array copies
+    unsigned char* pin;       // staging for the inputs, or nullptr: array-by-array copies
+    unsigned char* pin_out;   // staging for the outputs (needs the whole footprint to fit), or nullptr
     size_t in_lo = ~size_t(0), in_hi = 0, out_lo = ~size_t(0), out_hi = 0;
     struct Out {
         void* host;
         size_t off, bytes;
     } outs[8];
     int nout = 0;
-    Mover(void* workspace, size_t footprint)
-        : ws(static_cast<unsigned char*>(workspace)), pin(footprint <= STAGE_BYTES ? g_stage.get() : nullptr) {}
+    // inputs are carved first: they end at `in_end`; the outputs end at `footprint`
+    Mover(void* workspace, size_t in_end, size_t footprint)
+        : ws(static_cast<unsigned char*>(workspace)),
+          pin(in_end <= STAGE_BYTES ? g_stage.get() : nullptr),
+          pin_out(footprint <= STAGE_BYTES ? pin : nullptr) {}
     int in(const void* host, void* dev, size_t bytes) {
         if (!pin) {
             HIP_TRY(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, nullptr));
@@ -1008,7 +1013,7 @@ struct Mover {
         return PEM_OK;
     }
     int out(void* host, const void* dev, size_t bytes) {
-        if (!pin || nout == 8) {
+        if (!pin_out || nout == 8) {
             HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, nullptr));
             return PEM_OK;
         }
@@ -1019,9 +1024,10 @@ struct Mover {
         return PEM_OK;
     }
     int finish() {
-        if (pin && out_hi > out_lo) HIP_TRY(hipMemcpyAsync(pin + out_lo, ws + out_lo, out_hi - out_lo, hipMemcpyDeviceToHost, nullptr));
+        if (pin_out && out_hi > out_lo)
+            HIP_TRY(hipMemcpyAsync(pin_out + out_lo, ws + out_lo, out_hi - out_lo, hipMemcpyDeviceToHost, nullptr));
         HIP_TRY(hipStreamSynchronize(nullptr));
-        for (int i = 0; i < nout; ++i) memcpy(outs[i].host, pin + outs[i].off, outs[i].bytes);
+        for (int i = 0; i < nout; ++i) memcpy(outs[i].host, pin_out + outs[i].off, outs[i].bytes);
         return PEM_OK;
     }
 };
@@ -1301,8 +1307,10 @@ int pem_cathode_f64(size_t n, const double* P_b, const double* V_a, const double
         const size_t m = (n - off < chunk) ? n - off : chunk;
         Carver cv(g_ws.buf);
         double* d[7];
-        for (auto& p : d) p = cv.take<double>(chunk);
-        Mover mv(g_ws.buf, cv.off);
+        for (int i = 0; i < 6; ++i) d[i] = cv.take<double>(chunk);
+        const size_t in_end = cv.off;
+        d[6] = cv.take<double>(chunk);
+        Mover mv(g_ws.buf, in_end, cv.off);
         for (int i = 0; i < 6; ++i) PEM_TRY(mv.in(in[i] + off, d[i], m * 8));
         PEM_TRY(mv.flush_in());
         if (int rc = pem_cathode_f64_dev(m, d[0], d[1], d[2], d[3], d[4], d[5], torr2pa, d[6], nullptr)) return rc;
@@ -1329,8 +1337,9 @@ int pem_thruster_f64(size_t n, const double* V_a, const double* V_cc, const doub
         Carver cv(g_ws.buf);
         double *di[4], *dout[8];
         for (auto& p : di) p = cv.take<double>(chunk);
+        const size_t in_end = cv.off;
         for (int i = 0; i < 8; ++i) dout[i] = out[i] ? cv.take<double>(chunk) : nullptr;
-        Mover mv(g_ws.buf, cv.off);
+        Mover mv(g_ws.buf, in_end, cv.off);
         for (int i = 0; i < 4; ++i) PEM_TRY(mv.in(in[i] + off, di[i], m * 8));
         PEM_TRY(mv.flush_in());
         if (int rc = pem_thruster_f64_dev(m, di[0], di[1], di[2], di[3], dout[0], dout[1], dout[2], dout[3], dout[4],
@@ -1369,11 +1378,12 @@ int pem_plume_f64(size_t n, int n_radii, const double* radii, double torr2pa, co
         Carver cv(g_ws.buf);
         double* d[10];
         for (auto& p : d) p = cv.take<double>(chunk);
+        const size_t in_end = cv.off;
         double* dj = cv.take<double>(chunk * NANG * R);
         double* ddiv = cv.take<double>(chunk * R);
         double* dtc = cv.take<double>(chunk * R);
         uint8_t* dinv = cv.take<uint8_t>(chunk);
-        Mover mv(g_ws.buf, cv.off);
+        Mover mv(g_ws.buf, in_end, cv.off);
         for (int i = 0; i < 10; ++i)
             if (in[i]) PEM_TRY(mv.in(in[i] + off, d[i], m * 8));
         PEM_TRY(mv.flush_in());
@@ -1412,6 +1422,7 @@ int pem_coupled_f64(size_t n, double torr2pa, double radius, const double* P_b, 
         Carver cv(g_ws.buf);
         double* d[15];
         for (auto& p : d) p = cv.take<double>(chunk);
+        const size_t in_end = cv.off;
         double* dvcc = cv.take<double>(chunk);
         double* dib0 = cv.take<double>(chunk);
         double* dT = cv.take<double>(chunk);
@@ -1419,7 +1430,7 @@ int pem_coupled_f64(size_t n, double torr2pa, double radius, const double* P_b, 
         double* dtc = cv.take<double>(chunk);
         uint8_t* dinv = cv.take<uint8_t>(chunk);
         double* dj = cv.take<double>(chunk * NANG);   // last: without a profile the staged copy-back stops before it
-        Mover mv(g_ws.buf, cv.off);
+        Mover mv(g_ws.buf, in_end, cv.off);
         for (int i = 0; i < 15; ++i) PEM_TRY(mv.in(in[i] + off, d[i], m * 8));
         PEM_TRY(mv.flush_in());
         if (int rc = pem_coupled_f64_dev(m, torr2pa, radius, d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], d[9],
