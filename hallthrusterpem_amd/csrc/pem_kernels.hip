@@ -288,6 +288,7 @@ constexpr int LAT_RT = 8;   // latent columns of the fused compression mode (ran
 template <int L>
 constexpr int param_rows() { return 2 * L > NPARAM ? 2 * L : NPARAM; }   // rows 2c, 2c+1 are reused for the Simpson partials
 constexpr int TABLE_DOUBLES = 2 * NSIMP + PEM_NDI * PEM_NDC;
+constexpr int QPOLY_DOUBLES = (PEM_NDI + PEM_NQB) * PEM_NDC * 2;
 template <int L, int JMODE>
 constexpr int wave_lds_doubles() {
     return param_rows<L>() * WAVE +
@@ -325,9 +326,33 @@ struct WaveLds {
     const double* meas;      // fused likelihood: [n_cond*n_ang] records {weight, y, inv_std, k (integer bits)}, or nullptr
     const double2* simpson;  // [96] {cden, cnum}
     const double* poly;      // [32*12]
+    const double2* qpoly;    // reduced-QoI mode: [(32+64)*12] {Qd, Qn} coefficients of the Simpson functionals, or nullptr
     double* params;          // [9][64]
     double* tile;            // [S*91] + 2
 };
+
+// The two divergence integrals as functions of one beam width (tools/gen_tables.py, QPOLY): with
+// f_k = X1 e_k(a1) + X2 e_k(a2) the Simpson sums of plume.py:117-123 are X1 Qd(a1) + X2 Qd(a2) and X1 Qn(a1) + X2 Qn(a2).
+// Region A: |a| >= 0.25, row floor(2u), u = 1/a^2;  region B: QA_MIN <= |a| < 0.25, row NDI + floor(t),
+// t = (|a| - QA_MIN) * QB_SCALE;  x = 2 (t - row) - 1 in both.  Worst relative error 3.8e-16 (generator self-check).
+__device__ __forceinline__ void simpson_functionals(const double2* qpoly, double aa, double u, double& qd, double& qn) {
+    const bool wide = aa >= 0.25;
+    const double t = wide ? 2.0 * u : (aa - PEM_QA_MIN) * PEM_QB_SCALE;
+    const int last = wide ? PEM_NDI - 1 : PEM_NQB - 1;
+    int i = (int)t;                      // NaN -> 0; a sample that is not plain evaluates a row it will not use
+    i = i > last ? last : (i < 0 ? 0 : i);
+    const double x = 2.0 * (t - (double)i) - 1.0;
+    const double2* p = qpoly + ((wide ? 0 : PEM_NDI) + i) * PEM_NDC;
+    double2 acc = p[PEM_NDC - 1];
+#pragma unroll
+    for (int j = PEM_NDC - 2; j >= 0; --j) {
+        const double2 c = p[j];
+        acc.x = fma(acc.x, x, c.x);
+        acc.y = fma(acc.y, x, c.y);
+    }
+    qd = acc.x;
+    qn = acc.y;
+}
 
 // One 64-sample tile.  FULL = every sample of the tile exists (the steady state of the persistent loop:
 // no bounds checks and a fixed number of stores, so the compiler can count them); FULL = false is the
@@ -380,211 +405,237 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
     const double decay = exp(-rad * n_neutral * in.sigma);
     const double j_cex = I_B0 * (1.0 - decay) * inv_2pi_r2;
     const double base = I_B0 * decay * inv_r2;
-    // Gaussian recurrences: e_k = exp(-k^2 s), s = (h/a)^2; chunk starts at k = c*CH
-    const double s1 = (GRID_H * GRID_H) * u1, s2 = (GRID_H * GRID_H) * u2;
-    // a1 == 0: exp(-(0/0)^2) is NaN in the reference; the amplitudes carry it (A1 is NaN there)
-    params[0 * WAVE + lane] = base * A1;
-    params[1 * WAVE + lane] = base * A2;
-    params[2 * WAVE + lane] = j_cex;
-    params[3 * WAVE + lane] = exp_nonpos(-s1);
-    params[4 * WAVE + lane] = exp_nonpos(-(2.0 * CH) * s1);
-    params[5 * WAVE + lane] = exp_nonpos(-(double)(CH * CH) * s1);
-    params[6 * WAVE + lane] = exp_nonpos(-s2);
-    params[7 * WAVE + lane] = exp_nonpos(-(2.0 * CH) * s2);
-    params[8 * WAVE + lane] = exp_nonpos(-(double)(CH * CH) * s2);
     const unsigned long long a1_nonpos = __ballot(a1 <= 0.0);  // plume.py:105, first term
     unsigned long long inv_mask = 0;
-    wave_lds_sync();
+    double den = 0.0, num = 0.0;
+    // Reduced-QoI mode: nothing needs the 91 profile values themselves.  The two Simpson sums are linear in the beam
+    // amplitudes and depend on each beam only through its width -> two table look-ups per beam (simpson_functionals).
+    // What the loop would still decide is plume.py:105's `any(j_ion <= 0)`; with both amplitudes >= 0 and j_cex > 0 every
+    // j_ion[k] >= j_cex > 0, so the flag is `alpha1 <= 0` alone.  Such a "plain" sample takes its sums from the tables,
+    // any other one (NaN amplitudes, negative c0 or 1 - c0, beams narrower than QA_MIN) from the loop: a sample's result
+    // depends on that sample alone, however batches and shards cut the design.  The loop is skipped -- a wave-uniform
+    // branch -- when all 64 samples of the tile are plain, which under the PEM-v0 priors is every tile.
+    bool plain = false, table_tile = false;
+    double den_t = 0.0, num_t = 0.0;
+    if constexpr (JMODE == 0) {
+        const double aa1 = fabs(a1), aa2 = fabs(a2);
+        plain = aa1 >= PEM_QA_MIN && aa2 >= PEM_QA_MIN && base * A1 >= 0.0 && base * A2 >= 0.0 && j_cex > 0.0;
+        table_tile = __all(plain);
+        double d1, n1, d2, n2;
+        simpson_functionals(m.qpoly, aa1, u1, d1, n1);
+        simpson_functionals(m.qpoly, aa2, u2, d2, n2);
+        den_t = fma(base * A1, d1, (base * A2) * d2);
+        num_t = fma(base * A1, n1, (base * A2) * n2);
+        if (table_tile) inv_mask = a1_nonpos;
+    }
+    if (!table_tile) {
+        // Gaussian recurrences: e_k = exp(-k^2 s), s = (h/a)^2; chunk starts at k = c*CH
+        const double s1 = (GRID_H * GRID_H) * u1, s2 = (GRID_H * GRID_H) * u2;
+        // a1 == 0: exp(-(0/0)^2) is NaN in the reference; the amplitudes carry it (A1 is NaN there)
+        params[0 * WAVE + lane] = base * A1;
+        params[1 * WAVE + lane] = base * A2;
+        params[2 * WAVE + lane] = j_cex;
+        params[3 * WAVE + lane] = exp_nonpos(-s1);
+        params[4 * WAVE + lane] = exp_nonpos(-(2.0 * CH) * s1);
+        params[5 * WAVE + lane] = exp_nonpos(-(double)(CH * CH) * s1);
+        params[6 * WAVE + lane] = exp_nonpos(-s2);
+        params[7 * WAVE + lane] = exp_nonpos(-(2.0 * CH) * s2);
+        params[8 * WAVE + lane] = exp_nonpos(-(double)(CH * CH) * s2);
+        wave_lds_sync();
 
-    // ------------------------------ ROUNDS: L lanes per sample ------------------------------
+        // ------------------------------ ROUNDS: L lanes per sample ------------------------------
 #pragma unroll
-    for (int round = 0; round < L; ++round) {
-        const int smp = round * S + s;
-        double X1 = params[0 * WAVE + smp], X2 = params[1 * WAVE + smp];
-        const double jcex = params[2 * WAVE + smp];
-        const double r01 = params[3 * WAVE + smp], G1 = params[4 * WAVE + smp], E1 = params[5 * WAVE + smp];
-        const double r02 = params[6 * WAVE + smp], G2 = params[7 * WAVE + smp], E2 = params[8 * WAVE + smp];
-        // coarse recurrence to this lane's first angle k0 = c*CH:
-        //   e_{k0} = E^(c^2), r_{k0} = exp(-(2 k0 + 1) s) = r0 * G^c
-        double rr1 = r01, rr2 = r02, rho1 = E1, rho2 = E2;
-        const double E1sq = E1 * E1, E2sq = E2 * E2;
+        for (int round = 0; round < L; ++round) {
+            const int smp = round * S + s;
+            double X1 = params[0 * WAVE + smp], X2 = params[1 * WAVE + smp];
+            const double jcex = params[2 * WAVE + smp];
+            const double r01 = params[3 * WAVE + smp], G1 = params[4 * WAVE + smp], E1 = params[5 * WAVE + smp];
+            const double r02 = params[6 * WAVE + smp], G2 = params[7 * WAVE + smp], E2 = params[8 * WAVE + smp];
+            // coarse recurrence to this lane's first angle k0 = c*CH:
+            //   e_{k0} = E^(c^2), r_{k0} = exp(-(2 k0 + 1) s) = r0 * G^c
+            double rr1 = r01, rr2 = r02, rho1 = E1, rho2 = E2;
+            const double E1sq = E1 * E1, E2sq = E2 * E2;
 #pragma unroll
-        for (int i = 0; i < L - 1; ++i) {
-            if (i < c) {
-                X1 *= rho1;
-                rho1 *= E1sq;
-                rr1 *= G1;
-                X2 *= rho2;
-                rho2 *= E2sq;
-                rr2 *= G2;
+            for (int i = 0; i < L - 1; ++i) {
+                if (i < c) {
+                    X1 *= rho1;
+                    rho1 *= E1sq;
+                    rr1 *= G1;
+                    X2 *= rho2;
+                    rho2 *= E2sq;
+                    rr2 *= G2;
+                }
             }
-        }
-        const double q1 = r01 * r01, q2 = r02 * r02;
-        double den = 0.0, num = 0.0, lo = __builtin_inf();
-        double lat[LATENT ? LAT_RT : 1];
-        if constexpr (LATENT) {
+            const double q1 = r01 * r01, q2 = r02 * r02;
+            double den = 0.0, num = 0.0, lo = __builtin_inf();   // this lane's chunk of the round (shadows the tile sums)
+            double lat[LATENT ? LAT_RT : 1];
+            if constexpr (LATENT) {
 #pragma unroll
-            for (int r = 0; r < LAT_RT; ++r) lat[r] = 0.0;
-        }
-        // The weight reads are issued PF iterations ahead IN SOURCE ORDER: the tile stores in between are
-        // LDS stores the compiler must assume may alias the table, so it cannot hoist the reads itself.
-        constexpr int PF = 6;
-        double2 wq[CH];
-        if constexpr (LATENT) {
-            // a rolled loop: 23 inlined log10 evaluations in one basic block cost 512 registers and scratch
+                for (int r = 0; r < LAT_RT; ++r) lat[r] = 0.0;
+            }
+            // The weight reads are issued PF iterations ahead IN SOURCE ORDER: the tile stores in between are
+            // LDS stores the compiler must assume may alias the table, so it cannot hoist the reads itself.
+            constexpr int PF = 6;
+            double2 wq[CH];
+            if constexpr (LATENT) {
+                // a rolled loop: 23 inlined log10 evaluations in one basic block cost 512 registers and scratch
 #ifndef PEM_LATENT_UNROLL
 #define PEM_LATENT_UNROLL 4
 #endif
 #pragma unroll PEM_LATENT_UNROLL
-            for (int j = 0; j < CH; ++j) {
-                const double2 w = my_w[j];
-                const double f = X1 + X2;
-                const double ji = f + jcex;
-                const bool in_range = k0 + j < NANG;
-                lo = fmin(lo, in_range ? f : __builtin_inf());
-                den = fma(w.x, f, den);
-                num = fma(w.y, f, num);
-                // norm(j_ion[k]) times basis row k, straight from the registers; past 90 degrees the basis rows are
-                // zero, but 0 * log10(0) is not
-                double lj = io.log_norm ? pem::pem_log10(ji) : ji;
-                lj = in_range ? lj : 0.0;
-                const f64x2* brow = reinterpret_cast<const f64x2*>(m.basis + (k0 + j) * LAT_RT);
+                for (int j = 0; j < CH; ++j) {
+                    const double2 w = my_w[j];
+                    const double f = X1 + X2;
+                    const double ji = f + jcex;
+                    const bool in_range = k0 + j < NANG;
+                    lo = fmin(lo, in_range ? f : __builtin_inf());
+                    den = fma(w.x, f, den);
+                    num = fma(w.y, f, num);
+                    // norm(j_ion[k]) times basis row k, straight from the registers; past 90 degrees the basis rows are
+                    // zero, but 0 * log10(0) is not
+                    double lj = io.log_norm ? pem::pem_log10(ji) : ji;
+                    lj = in_range ? lj : 0.0;
+                    const f64x2* brow = reinterpret_cast<const f64x2*>(m.basis + (k0 + j) * LAT_RT);
 #pragma unroll
-                for (int r = 0; r < LAT_RT; r += 2) {
-                    const f64x2 b = brow[r >> 1];
-                    lat[r] = fma(lj, b.x, lat[r]);
-                    lat[r + 1] = fma(lj, b.y, lat[r + 1]);
+                    for (int r = 0; r < LAT_RT; r += 2) {
+                        const f64x2 b = brow[r >> 1];
+                        lat[r] = fma(lj, b.x, lat[r]);
+                        lat[r + 1] = fma(lj, b.y, lat[r + 1]);
+                    }
+                    X1 *= rr1;
+                    rr1 *= q1;
+                    X2 *= rr2;
+                    rr2 *= q2;
                 }
+            }
+#pragma unroll
+            for (int j = 0; WRITE_J && j < PF && j < CH; ++j) wq[j] = my_w[j];
+#pragma unroll
+            for (int j = 0; !LATENT && j < CH; ++j) {
+                if constexpr (!WRITE_J) wq[j] = my_w[j];   // no tile stores in between: the compiler schedules the reads
+                else if (j + PF < CH) wq[j + PF] = my_w[j + PF];
+                const double f = X1 + X2;     // j_beam + j_scat
+                const double ji = f + jcex;   // plume.py:102
+                if ((L - 1) * CH + j < NANG) {  // an angle every chunk has (compile-time after unrolling)
+                    if constexpr (WRITE_J) tile[s * NANG + k0 + j] = (JT)ji;
+                    lo = fmin(lo, WRITE_J ? ji : f);
+                } else {                        // past 90 degrees in the last chunk: store to the sink, skip the min
+                    const bool in_range = k0 + j < NANG;
+                    if constexpr (WRITE_J) tile[in_range ? s * NANG + k0 + j : TILE] = (JT)ji;
+                    lo = fmin(lo, in_range ? (WRITE_J ? ji : f) : __builtin_inf());
+                }
+                den = fma(wq[j].x, f, den);
+                num = fma(wq[j].y, f, num);
                 X1 *= rr1;
                 rr1 *= q1;
                 X2 *= rr2;
                 rr2 *= q2;
             }
-        }
+            // this round has read its nine parameter rows of sample `smp`: rows 2c, 2c+1 now carry the partial sums
+            params[(2 * c) * WAVE + smp] = den;
+            params[(2 * c + 1) * WAVE + smp] = num;
+            // plume.py:105: invalid if alpha1 <= 0 or any j_ion <= 0 (NaN compares false).  Without a stored profile
+            // the minimum runs over f and j_cex is added once: rounding is monotonic, min_k fl(f_k + c) = fl(min_k f_k + c).
+            unsigned long long bad = __ballot((WRITE_J ? lo : lo + jcex) <= 0.0);
 #pragma unroll
-        for (int j = 0; WRITE_J && j < PF && j < CH; ++j) wq[j] = my_w[j];
+            for (int sh = S; sh < WAVE; sh <<= 1) bad |= bad >> sh;   // fold the L chunk lanes of a sample onto bit s
+            bad = (bad | (a1_nonpos >> (round * S))) & ((S == 64) ? ~0ull : ((1ull << S) - 1));
+            inv_mask |= bad << (round * S);
+            if constexpr (LATENT) {
+                const long long smp_g = t * WAVE + smp;
+                const bool is_bad = (bad >> s) & 1;
+                const double fill = io.log_norm ? -20.0 : 1e-20;   // norm(1e-20): the profile of an invalid sample (plume.py:106)
 #pragma unroll
-        for (int j = 0; !LATENT && j < CH; ++j) {
-            if constexpr (!WRITE_J) wq[j] = my_w[j];   // no tile stores in between: the compiler schedules the reads
-            else if (j + PF < CH) wq[j + PF] = my_w[j + PF];
-            const double f = X1 + X2;     // j_beam + j_scat
-            const double ji = f + jcex;   // plume.py:102
-            if ((L - 1) * CH + j < NANG) {  // an angle every chunk has (compile-time after unrolling)
-                if constexpr (WRITE_J) tile[s * NANG + k0 + j] = (JT)ji;
-                lo = fmin(lo, WRITE_J ? ji : f);
-            } else {                        // past 90 degrees in the last chunk: store to the sink, skip the min
-                const bool in_range = k0 + j < NANG;
-                if constexpr (WRITE_J) tile[in_range ? s * NANG + k0 + j : TILE] = (JT)ji;
-                lo = fmin(lo, in_range ? (WRITE_J ? ji : f) : __builtin_inf());
+                for (int r = 0; r < LAT_RT; ++r) {
+                    double v = lat[r];
+#pragma unroll
+                    for (int sh = S; sh < WAVE; sh <<= 1) v += __shfl_xor(v, sh);   // the L chunk lanes of sample s
+                    if (is_bad) v = fill * m.basis[96 * LAT_RT + r];
+                    if (c == 0 && r < io.rank && (FULL || smp_g < io.n)) io.latent[smp_g * io.rank + r] = v;
+                }
             }
-            den = fma(wq[j].x, f, den);
-            num = fma(wq[j].y, f, num);
-            X1 *= rr1;
-            rr1 *= q1;
-            X2 *= rr2;
-            rr2 *= q2;
-        }
-        // this round has read its nine parameter rows of sample `smp`: rows 2c, 2c+1 now carry the partial sums
-        params[(2 * c) * WAVE + smp] = den;
-        params[(2 * c + 1) * WAVE + smp] = num;
-        // plume.py:105: invalid if alpha1 <= 0 or any j_ion <= 0 (NaN compares false).  Without a stored profile
-        // the minimum runs over f and j_cex is added once: rounding is monotonic, min_k fl(f_k + c) = fl(min_k f_k + c).
-        unsigned long long bad = __ballot((WRITE_J ? lo : lo + jcex) <= 0.0);
-#pragma unroll
-        for (int sh = S; sh < WAVE; sh <<= 1) bad |= bad >> sh;   // fold the L chunk lanes of a sample onto bit s
-        bad = (bad | (a1_nonpos >> (round * S))) & ((S == 64) ? ~0ull : ((1ull << S) - 1));
-        inv_mask |= bad << (round * S);
-        if constexpr (LATENT) {
-            const long long smp_g = t * WAVE + smp;
-            const bool is_bad = (bad >> s) & 1;
-            const double fill = io.log_norm ? -20.0 : 1e-20;   // norm(1e-20): the profile of an invalid sample (plume.py:106)
-#pragma unroll
-            for (int r = 0; r < LAT_RT; ++r) {
-                double v = lat[r];
-#pragma unroll
-                for (int sh = S; sh < WAVE; sh <<= 1) v += __shfl_xor(v, sh);   // the L chunk lanes of sample s
-                if (is_bad) v = fill * m.basis[96 * LAT_RT + r];
-                if (c == 0 && r < io.rank && (FULL || smp_g < io.n)) io.latent[smp_g * io.rank + r] = v;
-            }
-        }
-        if constexpr (WRITE_J) {
-            if ((bad >> s) & 1) {  // plume.py:106: the whole profile of an invalid sample becomes 1e-20 (rare)
-                for (int j = 0; j < CH; ++j)
-                    if (k0 + j < NANG) tile[s * NANG + k0 + j] = (JT)1e-20;
-            }
-            wave_lds_sync();
-            const long long first = t * WAVE + (long long)round * S;
-            if constexpr (JMODE == 3) {
-                static_assert(JMODE != 3 || 2 * L < param_rows<L>(), "row 2L of `params` carries the likelihood sum");
-                // measured current densities against the staged profile: lane (s, c) takes measurements c, c+L, ...
-                // of its sample's condition (sample index mod n_cond); the sample's sum goes to row 2L of `params`
-                const unsigned cond = ((unsigned)((t * WAVE) % io.n_cond) + (unsigned)(round * S + s)) % (unsigned)io.n_cond;
-                const double4* mt = reinterpret_cast<const double4*>(m.meas) + cond * (io.n_ang | 1);   // {weight, y, 1/std, k}
-                const JT* row = tile + s * NANG;
-                double acc = 0.0;
+            if constexpr (WRITE_J) {
+                if ((bad >> s) & 1) {  // plume.py:106: the whole profile of an invalid sample becomes 1e-20 (rare)
+                    for (int j = 0; j < CH; ++j)
+                        if (k0 + j < NANG) tile[s * NANG + k0 + j] = (JT)1e-20;
+                }
+                wave_lds_sync();
+                const long long first = t * WAVE + (long long)round * S;
+                if constexpr (JMODE == 3) {
+                    static_assert(JMODE != 3 || 2 * L < param_rows<L>(), "row 2L of `params` carries the likelihood sum");
+                    // measured current densities against the staged profile: lane (s, c) takes measurements c, c+L, ...
+                    // of its sample's condition (sample index mod n_cond); the sample's sum goes to row 2L of `params`
+                    const unsigned cond = ((unsigned)((t * WAVE) % io.n_cond) + (unsigned)(round * S + s)) % (unsigned)io.n_cond;
+                    const double4* mt = reinterpret_cast<const double4*>(m.meas) + cond * (io.n_ang | 1);   // {weight, y, 1/std, k}
+                    const JT* row = tile + s * NANG;
+                    double acc = 0.0;
 #ifndef PEM_LOGLIK_MU
 #define PEM_LOGLIK_MU 2
 #endif
-                constexpr int MU = PEM_LOGLIK_MU;   // records in flight per lane: the k -> row[k] chain is two LDS latencies deep
-                for (int a0 = c; a0 < io.n_ang; a0 += MU * L) {
-                    double4 e[MU];
-                    double lo_v[MU], hi_v[MU];
+                    constexpr int MU = PEM_LOGLIK_MU;   // records in flight per lane: the k -> row[k] chain is two LDS latencies deep
+                    for (int a0 = c; a0 < io.n_ang; a0 += MU * L) {
+                        double4 e[MU];
+                        double lo_v[MU], hi_v[MU];
 #pragma unroll
-                    for (int u = 0; u < MU; ++u) e[u] = mt[a0 + u * L < io.n_ang ? a0 + u * L : a0];
+                        for (int u = 0; u < MU; ++u) e[u] = mt[a0 + u * L < io.n_ang ? a0 + u * L : a0];
 #pragma unroll
-                    for (int u = 0; u < MU; ++u) {
-                        const int k = __double_as_longlong(e[u].w) & 0x7f;
-                        lo_v[u] = row[k];
-                        hi_v[u] = row[k + 1];
+                        for (int u = 0; u < MU; ++u) {
+                            const int k = __double_as_longlong(e[u].w) & 0x7f;
+                            lo_v[u] = row[k];
+                            hi_v[u] = row[k + 1];
+                        }
+#pragma unroll
+                        for (int u = 0; u < MU; ++u) {
+                            const double model = fma(e[u].x, hi_v[u] - lo_v[u], lo_v[u]);
+                            const double z = (e[u].y - model) * e[u].z;
+                            if (a0 + u * L < io.n_ang) acc = fma(-0.5 * z, z, acc);
+                        }
                     }
 #pragma unroll
-                    for (int u = 0; u < MU; ++u) {
-                        const double model = fma(e[u].x, hi_v[u] - lo_v[u], lo_v[u]);
-                        const double z = (e[u].y - model) * e[u].z;
-                        if (a0 + u * L < io.n_ang) acc = fma(-0.5 * z, z, acc);
-                    }
+                    for (int sh = S; sh < WAVE; sh <<= 1) acc += __shfl_xor(acc, sh);   // the L chunk lanes of sample s
+                    if (c == 0) params[(2 * L) * WAVE + smp] = acc;
+                    wave_lds_sync();
+                    continue;
                 }
-#pragma unroll
-                for (int sh = S; sh < WAVE; sh <<= 1) acc += __shfl_xor(acc, sh);   // the L chunk lanes of sample s
-                if (c == 0) params[(2 * L) * WAVE + smp] = acc;
-                wave_lds_sync();
-                continue;
-            }
-            // the round's S*91 values are one contiguous, 16-byte aligned block of j_ion
-            JT* jbase;
-            if constexpr (JMODE == 2) jbase = io.j_ion_f32; else jbase = io.j_ion;
-            if constexpr (FULL) {
-                f64x2* dst2 = reinterpret_cast<f64x2*>(jbase + first * NANG);
-                const f64x2* srcv = reinterpret_cast<const f64x2*>(tile);
-#pragma unroll
-                for (int it = 0; it < PAIRS / WAVE; ++it) stream_store(srcv[it * WAVE + lane], &dst2[it * WAVE + lane]);
-                if (PAIRS % WAVE != 0 && lane < PAIRS % WAVE)
-                    stream_store(srcv[(PAIRS / WAVE) * WAVE + lane], &dst2[(PAIRS / WAVE) * WAVE + lane]);
-            } else {
-                long long valid = (io.n - first) * NANG;   // values of this round that exist
-                if (valid > TILE) valid = TILE;
-                if (valid > 0) {
-                    JT* dst = jbase + first * NANG;
-                    f64x2* dst2 = reinterpret_cast<f64x2*>(dst);
+                // the round's S*91 values are one contiguous, 16-byte aligned block of j_ion
+                JT* jbase;
+                if constexpr (JMODE == 2) jbase = io.j_ion_f32; else jbase = io.j_ion;
+                if constexpr (FULL) {
+                    f64x2* dst2 = reinterpret_cast<f64x2*>(jbase + first * NANG);
                     const f64x2* srcv = reinterpret_cast<const f64x2*>(tile);
-                    const int pieces = (int)(valid / PER16);
-                    for (int i = lane; i < pieces; i += WAVE) dst2[i] = srcv[i];
-                    const int rest = (int)(valid - (long long)pieces * PER16);
-                    if (lane < rest) dst[pieces * PER16 + lane] = tile[pieces * PER16 + lane];
+#pragma unroll
+                    for (int it = 0; it < PAIRS / WAVE; ++it) stream_store(srcv[it * WAVE + lane], &dst2[it * WAVE + lane]);
+                    if (PAIRS % WAVE != 0 && lane < PAIRS % WAVE)
+                        stream_store(srcv[(PAIRS / WAVE) * WAVE + lane], &dst2[(PAIRS / WAVE) * WAVE + lane]);
+                } else {
+                    long long valid = (io.n - first) * NANG;   // values of this round that exist
+                    if (valid > TILE) valid = TILE;
+                    if (valid > 0) {
+                        JT* dst = jbase + first * NANG;
+                        f64x2* dst2 = reinterpret_cast<f64x2*>(dst);
+                        const f64x2* srcv = reinterpret_cast<const f64x2*>(tile);
+                        const int pieces = (int)(valid / PER16);
+                        for (int i = lane; i < pieces; i += WAVE) dst2[i] = srcv[i];
+                        const int rest = (int)(valid - (long long)pieces * PER16);
+                        if (lane < rest) dst[pieces * PER16 + lane] = tile[pieces * PER16 + lane];
+                    }
                 }
+                wave_lds_sync();
             }
-            wave_lds_sync();
         }
+        wave_lds_sync();
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            den += params[(2 * i) * WAVE + lane];
+            num += params[(2 * i + 1) * WAVE + lane];
+        }
+    }   // !table_tile
+    if constexpr (JMODE == 0) {
+        den = plain ? den_t : den;
+        num = plain ? num_t : num;
     }
-    wave_lds_sync();
 
     // ------------------------------ EPILOGUE: one lane per sample ------------------------------
-    double den = 0.0, num = 0.0;
-#pragma unroll
-    for (int i = 0; i < L; ++i) {
-        den += params[(2 * i) * WAVE + lane];
-        num += params[(2 * i + 1) * WAVE + lane];
-    }
     double cos_div = num / den;  // plume.py:124-127
     if (cos_div == __builtin_inf()) cos_div = __builtin_nan("");
     if constexpr (JMODE == 3) {
@@ -617,6 +668,12 @@ __global__ __launch_bounds__(WAVE * WPB) void plume_r1_kernel(PlumeIO io, Couple
     m.poly = tab_poly;
     m.params = lds + TABLE_DOUBLES + wave * wave_lds_doubles<L, JMODE>();   // [rows][64], private to this wave
     m.tile = m.params + param_rows<L>() * WAVE;                               // [S*91] + sink
+    m.qpoly = nullptr;
+    if constexpr (JMODE == 0) {   // Simpson-functional tables behind the per-wave regions
+        double* q = lds + TABLE_DOUBLES + WPB * wave_lds_doubles<L, JMODE>();
+        for (int i = tid; i < QPOLY_DOUBLES; i += WAVE * WPB) q[i] = PEM_QPOLY[i];
+        m.qpoly = reinterpret_cast<const double2*>(q);
+    }
     m.basis = nullptr;
     if constexpr (JMODE == 4) {   // zero-padded basis [96][LAT_RT] + column sums, behind the per-wave regions
         double* bas = lds + TABLE_DOUBLES + WPB * wave_lds_doubles<L, JMODE>();
@@ -899,6 +956,7 @@ int launch_r1(const PlumeIO& io, const CoupledIO& cio, hipStream_t st, const McD
     size_t lds = (size_t)fast_lds_doubles<L, JMODE>() * 8;
     if (JMODE == 3) lds += (size_t)io.n_cond * (io.n_ang | 1) * 32;
     if (JMODE == 4) lds += (size_t)(96 + 1) * LAT_RT * 8;
+    if (JMODE == 0) lds += (size_t)QPOLY_DOUBLES * 8;
     const long long ntiles = (io.n + WAVE - 1) / WAVE;
     unsigned grid = 0;
     if (int rc = fast_grid(lds, ntiles, &grid)) return rc;

@@ -174,8 +174,14 @@ def test_coupled_vs_oracle(pem, oc, n):
     # reduced-QoI mode returns the same scalars without ever writing the profile
     red = pem_v0_coupled(x, profile=False)
     assert 'j_ion' not in red
-    for k in ('V_cc', 'I_B0', 'T', 'div_angle', 'T_c'):
+    for k in ('V_cc', 'I_B0', 'T'):
         assert np.array_equal(red[k], got[k], equal_nan=True), k
+    # ... the divergence integrals come from the Simpson-functional tables there (csrc: simpson_functionals), not from
+    # the 91-term sums: held to the oracle like the full mode, and to the full mode within rounding
+    assert div_err(red['div_angle'], want['div_angle']) <= RTOL and rel_err(red['T_c'], want['T_c']) <= RTOL
+    # (arccos amplifies the ~1e-15 difference of cos_div by 1 / div_angle^2: narrow beams reach a few 1e-13)
+    assert div_err(red['div_angle'], got['div_angle']) <= 1e-11 and rel_err(red['T_c'], got['T_c']) <= 1e-12
+    assert np.array_equal(red['invalid'], got['invalid'])
 
 
 def test_empty_batch(pem):
@@ -400,3 +406,41 @@ def test_host_entry_points_from_a_thread_pool(pem, oc):
                 for k in a:
                     if k != 'j_ion_coords':
                         assert np.array_equal(a[k], b[k], equal_nan=True), k
+
+
+def test_reduced_mode_table_and_loop_paths_agree_sample_by_sample(pem, oc):
+    """Reduced-QoI mode: "plain" samples (amplitudes >= 0, j_cex > 0, beams wider than QA_MIN) take the divergence
+    integrals from tables, the others from the 91-term loop -- per sample, so a result never depends on which other
+    samples share its tile.  Mixed tiles, narrow beams on both sides of QA_MIN, invalid and NaN samples vs the oracle."""
+    import torch
+    from hallthrusterpem_amd.batch import CoupledBatch
+    from hallthrusterpem_amd.models.coupled import COUPLED_INPUTS
+    n = 64 * 40 + 17
+    x = coupled_inputs(n, seed=9)
+    rng = np.random.default_rng(9)
+    row = {k: i for i, k in enumerate(COUPLED_INPUTS)}
+    x['c2'] = np.where(rng.random(n) < 0.5, 0.0, x['c2'])
+    narrow = rng.random(n) < 0.3
+    x['c3'] = np.where(narrow, rng.uniform(0.005, 0.06, n), x['c3'])          # alpha1 around QA_MIN = 0.03
+    x['c2'] = np.where(narrow, 0.0, x['c2'])
+    x['c0'] = np.where(rng.random(n) < 0.1, rng.uniform(-0.5, 1.5, n), x['c0'])   # negative amplitudes: loop path
+    x['c3'][5], x['c2'][5] = -0.3, 0.0                                        # alpha1 <= 0: invalid
+    x['c1'][70] = np.nan
+    x['c3'][130:194] = 0.7                                                    # one whole tile of plain samples
+    x['c2'][130:194], x['c0'][130:194] = 0.0, 0.4
+    want = oc.coupled(x, pem.constants.TORR_2_PA)
+    b = CoupledBatch(n, profile=False)
+    b.set_inputs(x)
+    b.run()
+    torch.cuda.synchronize()
+    got = {k: v.cpu().numpy() for k, v in b.outputs().items()}
+    assert np.array_equal(got['invalid'], want['invalid']) and got['invalid'][5] and got['invalid'].sum() > 20
+    assert np.array_equal(np.isnan(got['div_angle']), np.isnan(want['div_angle'])) and np.isnan(got['div_angle'][70])
+    assert div_err(got['div_angle'], want['div_angle']) <= RTOL and rel_err(got['T_c'], want['T_c']) <= RTOL
+    # the same samples in another order (other tile mates): bit-identical results
+    perm = rng.permutation(n)
+    b2 = CoupledBatch(n, profile=False)
+    b2.inputs.copy_(b.inputs[:, torch.from_numpy(perm).cuda()])
+    b2.run()
+    torch.cuda.synchronize()
+    assert np.array_equal(b2.qoi.cpu().numpy(), b.qoi.cpu().numpy()[:, perm], equal_nan=True)

@@ -18,6 +18,13 @@ section 0).  Two tables evaluate it without any complex arithmetic:
               composite-Simpson weight scipy.integrate.simpson(x=alpha_rad) gives point m (irregular-
               spacing formula, evaluated in the same double arithmetic).
 
+  * QPOLY     the two divergence integrals as FUNCTIONS of the beam width.  With f_k = X1 e_k(a1) + X2 e_k(a2),
+              e_k(a) = exp(-(k h / a)^2), the Simpson sums are den = X1 Qd(a1) + X2 Qd(a2), num = X1 Qn(a1) + X2 Qn(a2)
+              with Qd(a) = sum_k CDEN[k] e_k(a), Qn(a) = sum_k CNUM[k] e_k(a): when no profile is wanted the 91-term
+              loop is two table look-ups per beam.  Region A, u = 1/a^2 in [0, 16] like DPOLY (32 intervals);
+              region B, |a| in [QA_MIN, 0.25), 64 equal intervals in |a|; degree 11 both; coefficients of Qd and Qn
+              interleaved: QPOLY[(interval*NDC + j)*2 + {0, 1}].  Below QA_MIN the kernel runs the loop.
+
 Run:  python tools/gen_tables.py   (rewrites the header, ~40 s; the header is committed)
 """
 from pathlib import Path
@@ -30,6 +37,8 @@ NANGLE = 91
 NDI = 32      # intervals of width 1/2 in u = 1/alpha^2 covering [0, 16]
 NDC = 12      # coefficients per interval (degree 11)
 NDAW = 10
+NQB = 64          # region-B intervals of QPOLY
+QA_MIN = 0.03     # below this beam width the Simpson functionals are summed term by term
 
 
 def hexd(x):
@@ -65,6 +74,47 @@ def dpoly_tables():
     return rows
 
 
+def cheb_monomials(f, lo, hi):
+    """Degree NDC-1 Chebyshev interpolant of f on [lo, hi] as monomial coefficients in x in [-1, 1]."""
+    T = [[mp.mpf(1)], [mp.mpf(0), mp.mpf(1)]]
+    for j in range(2, NDC):
+        cur = [mp.mpf(0)] + [2 * c for c in T[j - 1]]
+        for k, c in enumerate(T[j - 2]):
+            cur[k] -= c
+        T.append(cur)
+    nodes = [mp.cos(mp.pi * (k + mp.mpf(1) / 2) / NDC) for k in range(NDC)]
+    mid, half = (lo + hi) / 2, (hi - lo) / 2
+    vals = [f(mid + half * x) for x in nodes]
+    cheb = [sum(vals[k] * mp.cos(mp.pi * j * (k + mp.mpf(1) / 2) / NDC) for k in range(NDC)) * 2 / NDC for j in range(NDC)]
+    cheb[0] /= 2
+    mono = [mp.mpf(0)] * NDC
+    for j, cj in enumerate(cheb):
+        for k, tk in enumerate(T[j]):
+            mono[k] += cj * tk
+    return mono
+
+
+def q_functional(c, u):
+    """sum_k c[k] exp(-k^2 h^2 u) at 50 digits (c: the double weights the kernel uses, taken exactly)."""
+    s = (mp.pi / 180) ** 2 * u
+    return mp.fsum(mp.mpf(float(c[k])) * mp.exp(-(k * k) * s) for k in range(NANGLE))
+
+
+def qpoly_tables(cden, cnum):
+    mp.mp.dps = 50
+    rows = []
+    for i in range(NDI):                                         # region A: u in [i/2, (i+1)/2]
+        lo, hi = mp.mpf(i) / 2, mp.mpf(i + 1) / 2
+        rows.append((cheb_monomials(lambda u: q_functional(cden, u), lo, hi),
+                     cheb_monomials(lambda u: q_functional(cnum, u), lo, hi)))
+    width = (mp.mpf('0.25') - mp.mpf(QA_MIN)) / NQB
+    for i in range(NQB):                                         # region B: |a| in [QA_MIN + i w, QA_MIN + (i+1) w]
+        lo, hi = mp.mpf(QA_MIN) + i * width, mp.mpf(QA_MIN) + (i + 1) * width
+        rows.append((cheb_monomials(lambda a: q_functional(cden, 1 / (a * a)), lo, hi),
+                     cheb_monomials(lambda a: q_functional(cnum, 1 / (a * a)), lo, hi)))
+    return rows
+
+
 def simpson_weights(x):
     n = len(x)
     w = np.zeros(n)
@@ -89,6 +139,8 @@ def main():
         m = NANGLE - 1 - k
         cden[k] = w[m] * np.cos(alpha[m])
         cnum[k] = cden[k] * np.sin(alpha[m])
+
+    qpoly = qpoly_tables(cden, cnum)
 
     daw = []
     dfact = mp.mpf(1)
@@ -118,6 +170,15 @@ def main():
               f'PEM_TABLE_DECL double PEM_DPOLY[{NDI * NDC}] = {{']
     for row in dpoly:
         lines.append('    ' + ', '.join(hexd(v) for v in row) + ',')
+    lines += ['};', '',
+              '// Qd(a), Qn(a): the Simpson functionals of the divergence integrals (see the generator); rows 0..NDI-1: u in',
+              '// [0,16] as DPOLY; rows NDI..NDI+NQB-1: |a| in [QA_MIN, 0.25), x = 2 (t - i) - 1, t = (|a| - QA_MIN) * QB_SCALE',
+              f'#define PEM_NQB {NQB}',
+              f'#define PEM_QA_MIN {QA_MIN!r}',
+              f'#define PEM_QB_SCALE {float(NQB / (0.25 - QA_MIN))!r}',
+              f'PEM_TABLE_DECL double PEM_QPOLY[{(NDI + NQB) * NDC * 2}] = {{']
+    for qd, qn in qpoly:
+        lines.append('    ' + ', '.join(f'{hexd(a)}, {hexd(b)}' for a, b in zip(qd, qn)) + ',')
     lines += ['};', '']
     OUT.write_text('\n'.join(lines))
     print('wrote', OUT)
@@ -142,6 +203,27 @@ def main():
         got = np.pi * a * a * sum(float(c) * y ** n for n, c in enumerate(daw))
         worst = max(worst, abs(got - ex) / ex)
     print('worst relative error of the small-alpha series:', mp.nstr(worst, 3))
+    # QPOLY evaluated as the kernel does (double Horner, both regions) against the 40-digit sums
+    worst = 0
+    scale = float(NQB / (0.25 - QA_MIN))
+    for a in np.concatenate([rng.uniform(QA_MIN, 0.25, 200), 1 / np.sqrt(rng.uniform(1e-6, 16, 300)),
+                             [QA_MIN, 0.25 - 1e-15, 0.25, 1.5707963, 15.7, 53.0, 1e6]]):
+        if a >= 0.25:
+            u = 1.0 / (a * a)
+            i = min(int(2 * u), NDI - 1)
+            x = 4 * u - 2 * i - 1
+        else:
+            t = (a - QA_MIN) * scale
+            i = min(int(t), NQB - 1)
+            x = 2 * (t - i) - 1
+            i += NDI
+        for which, c in enumerate((cden, cnum)):
+            acc = 0.0
+            for cj in reversed([float(v) for v in qpoly[i][which]]):
+                acc = acc * x + cj
+            ex = q_functional(c, 1 / mp.mpf(float(a)) ** 2)
+            worst = max(worst, abs(acc - ex) / abs(ex))
+    print('worst relative error of the Qd/Qn polynomial tables:', mp.nstr(worst, 3))
 
 
 if __name__ == '__main__':
