@@ -244,19 +244,23 @@ __device__ __forceinline__ SampleIn<true> generate_sample(const McDesign& mc, lo
     const unsigned long long g = mc.first + (unsigned long long)g_local;
     const unsigned int k0 = (unsigned int)mc.seed, k1 = (unsigned int)(mc.seed >> 32);
     double x[16];
+    // All eight Philox blocks first: they are independent chains of quarter-rate 32x32 multiplies, and the out-of-line
+    // transform calls between them would keep the scheduler from interleaving them.
+    double u[16];
 #pragma unroll
     for (int pair = 0; pair < 8; ++pair) {
         // the two dimensions of a pair may come from different streams in a Saltelli block (wave-uniform choice)
         const unsigned int st0 = mc.stream + ((mc.swap_dim == -2 || mc.swap_dim == 2 * pair) ? 1u : 0u);
         const unsigned int st1 = mc.stream + ((mc.swap_dim == -2 || mc.swap_dim == 2 * pair + 1) ? 1u : 0u);
         const pem::Philox4 r = pem::philox4x32_10((unsigned int)g, (unsigned int)(g >> 32), (unsigned int)pair, st0, k0, k1);
-        x[2 * pair] = transform_call(mc.kind[2 * pair], mc.a[2 * pair], mc.b[2 * pair], pem::u53(r.x, r.y));
-        if (2 * pair + 1 < 15) {
-            pem::Philox4 r1 = r;
-            if (st1 != st0) r1 = pem::philox4x32_10((unsigned int)g, (unsigned int)(g >> 32), (unsigned int)pair, st1, k0, k1);
-            x[2 * pair + 1] = transform_call(mc.kind[2 * pair + 1], mc.a[2 * pair + 1], mc.b[2 * pair + 1], pem::u53(r1.z, r1.w));
-        }
+        pem::Philox4 r1 = r;
+        if (2 * pair + 1 < 15 && st1 != st0)
+            r1 = pem::philox4x32_10((unsigned int)g, (unsigned int)(g >> 32), (unsigned int)pair, st1, k0, k1);
+        u[2 * pair] = pem::u53(r.x, r.y);
+        u[2 * pair + 1] = pem::u53(r1.z, r1.w);
     }
+#pragma unroll
+    for (int d = 0; d < 15; ++d) x[d] = transform_call(mc.kind[d], mc.a[d], mc.b[d], u[d]);
     if (mc.x_out) {
 #pragma unroll
         for (int d = 0; d < 15; ++d) mc.x_out[(size_t)d * mc.ld + g_local] = x[d];

@@ -31,6 +31,9 @@ using pem::philox4x32_10;
 using pem::transform;
 using pem::u53;
 
+// out of line: inlined, the library exp / normcdfinv bodies cost the kernel 438 registers (one wave per SIMD)
+__device__ __attribute__((noinline)) double transform_call(int kind, double a, double b, double u) { return transform(kind, a, b, u); }
+
 // keyed bijection of [0, n): 4-round Feistel network on 2*h bits with cycle walking (Latin-hypercube strata)
 __device__ __forceinline__ uint64_t feistel_permute(uint64_t i, uint64_t n, int half_bits, uint32_t k0, uint32_t k1,
                                                     uint32_t dim) {
@@ -59,20 +62,21 @@ __global__ __launch_bounds__(256) void sample_kernel(long long n, uint64_t first
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const uint64_t g = first + (uint64_t)i;
         for (int d0 = 0; d0 < ndim; d0 += 2) {
-            double u[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int d = d0 + h;
-                const uint32_t st = stream + ((swap_dim == -2 || swap_dim == d) ? 1u : 0u);
-                const Philox4 r = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)(d0 >> 1), st, k0, k1);
-                u[h] = h == 0 ? u53(r.x, r.y) : u53(r.z, r.w);
-                if (mode == 1) {   // stratum pi_d(g) of n_total, jittered by u
-                    const uint64_t cell = feistel_permute(g, n_total, half_bits, k0, k1 ^ st, (uint32_t)d);
-                    u[h] = ((double)cell + u[h]) / (double)n_total;
-                }
+            // one Philox call serves both dimensions of the pair unless a Saltelli block draws them from different
+            // streams (a wave-uniform choice)
+            const uint32_t st0 = stream + ((swap_dim == -2 || swap_dim == d0) ? 1u : 0u);
+            const uint32_t st1 = stream + ((swap_dim == -2 || swap_dim == d0 + 1) ? 1u : 0u);
+            const Philox4 r0 = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)(d0 >> 1), st0, k0, k1);
+            Philox4 r1 = r0;
+            if (st1 != st0) r1 = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)(d0 >> 1), st1, k0, k1);
+            double u[2] = {u53(r0.x, r0.y), u53(r1.z, r1.w)};
+            if (mode == 1) {   // stratum pi_d(g) of n_total, jittered by u
+                u[0] = ((double)feistel_permute(g, n_total, half_bits, k0, k1 ^ st0, (uint32_t)d0) + u[0]) / (double)n_total;
+                if (d0 + 1 < ndim)
+                    u[1] = ((double)feistel_permute(g, n_total, half_bits, k0, k1 ^ st1, (uint32_t)(d0 + 1)) + u[1]) / (double)n_total;
             }
-            out[(size_t)d0 * ld + i] = transform(tab.kind[d0], tab.a[d0], tab.b[d0], u[0]);
-            if (d0 + 1 < ndim) out[(size_t)(d0 + 1) * ld + i] = transform(tab.kind[d0 + 1], tab.a[d0 + 1], tab.b[d0 + 1], u[1]);
+            out[(size_t)d0 * ld + i] = transform_call(tab.kind[d0], tab.a[d0], tab.b[d0], u[0]);
+            if (d0 + 1 < ndim) out[(size_t)(d0 + 1) * ld + i] = transform_call(tab.kind[d0 + 1], tab.a[d0 + 1], tab.b[d0 + 1], u[1]);
         }
     }
 }
