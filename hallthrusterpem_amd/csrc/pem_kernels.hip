@@ -420,16 +420,9 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
     // depends on that sample alone, however batches and shards cut the design.  The loop is skipped -- a wave-uniform
     // branch -- when all 64 samples of the tile are plain, which under the PEM-v0 priors is every tile.
     bool plain = false, table_tile = false;
-    double den_t = 0.0, num_t = 0.0;
     if constexpr (JMODE == 0) {
-        const double aa1 = fabs(a1), aa2 = fabs(a2);
-        plain = aa1 >= PEM_QA_MIN && aa2 >= PEM_QA_MIN && base * A1 >= 0.0 && base * A2 >= 0.0 && j_cex > 0.0;
+        plain = fabs(a1) >= PEM_QA_MIN && fabs(a2) >= PEM_QA_MIN && base * A1 >= 0.0 && base * A2 >= 0.0 && j_cex > 0.0;
         table_tile = __all(plain);
-        double d1, n1, d2, n2;
-        simpson_functionals(m.qpoly, aa1, u1, d1, n1);
-        simpson_functionals(m.qpoly, aa2, u2, d2, n2);
-        den_t = fma(base * A1, d1, (base * A2) * d2);
-        num_t = fma(base * A1, n1, (base * A2) * n2);
         if (table_tile) inv_mask = a1_nonpos;
     }
     if (!table_tile) {
@@ -634,9 +627,12 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
             num += params[(2 * i + 1) * WAVE + lane];
         }
     }   // !table_tile
-    if constexpr (JMODE == 0) {
-        den = plain ? den_t : den;
-        num = plain ? num_t : num;
+    if constexpr (JMODE == 0) {   // after the loop, so that nothing of it stays live across the loop's 213 registers
+        double d1, n1, d2, n2;
+        simpson_functionals(m.qpoly, fabs(a1), u1, d1, n1);
+        simpson_functionals(m.qpoly, fabs(a2), u2, d2, n2);
+        den = plain ? fma(base * A1, d1, (base * A2) * d2) : den;
+        num = plain ? fma(base * A1, n1, (base * A2) * n2) : num;
     }
 
     // ------------------------------ EPILOGUE: one lane per sample ------------------------------
@@ -935,14 +931,14 @@ using pem::fail;
 
 // persistent grid of the fast kernel: workgroups of WPB waves, as many as the LDS admits on every CU, capped at
 // two waves per SIMD
-int fast_grid(size_t lds_bytes, long long ntiles, unsigned* grid) {
+int fast_grid(size_t lds_bytes, long long ntiles, unsigned* grid, int max_waves_per_cu = 8) {
     static int cus[64] = {0};
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return fail(PEM_ERR_INVALID_ARG, "device index %d out of range", dev);
     if (cus[dev] == 0) HIP_TRY(hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev));
     long long per_cu = (long long)(160 * 1024 / lds_bytes);   // workgroups per CU
-    if (per_cu > 8 / WPB) per_cu = 8 / WPB;
+    if (per_cu > max_waves_per_cu / WPB) per_cu = max_waves_per_cu / WPB;
     if (const char* e = getenv("PEM_WAVES_PER_CU")) {          // tuning/experiments only
         const long long v = atoll(e) / WPB;
         if (v >= 1 && v < per_cu) per_cu = v;
@@ -963,7 +959,9 @@ int launch_r1(const PlumeIO& io, const CoupledIO& cio, hipStream_t st, const McD
     if (JMODE == 0) lds += (size_t)QPOLY_DOUBLES * 8;
     const long long ntiles = (io.n + WAVE - 1) / WAVE;
     unsigned grid = 0;
-    if (int rc = fast_grid(lds, ntiles, &grid)) return rc;
+    // the fused Monte-Carlo reduced-QoI kernel needs 165 registers: three waves per SIMD help it hide Philox's
+    // quarter-rate multiplies; every other instantiation needs more than 170 and gets two
+    if (int rc = fast_grid(lds, ntiles, &grid, (MC && JMODE == 0) ? 12 : 8)) return rc;
     auto kern = plume_r1_kernel<L, COUPLED, JMODE, MC>;
     if (lds > 64 * 1024) {
         static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
