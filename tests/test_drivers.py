@@ -188,3 +188,35 @@ def test_config1_cathode_lhs_design_on_device():
     want = oc.cathode(*[xh[i] for i in range(6)], constants.TORR_2_PA)
     assert rel_err(got.cpu().numpy(), want) <= 1e-10
     assert float(got.min()) >= 0 and float(got.max()) <= 100
+
+
+def _sobol_rank(rank, world, port, n_base, out_dir):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        res = drivers.sobol_indices(n_base, seed=5, fixed={'P_b': 1e-5, 'V_a': 300.0, 'mdot_a': 5e-6}, batch_size=4096)
+        np.savez(f'{out_dir}/rank{rank}.npz', **{f'{a}_{k}': v.cpu().numpy() for a in ('S1', 'ST') for k, v in res[a].items()})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sobol_indices_sharded_over_two_ranks(tmp_path):
+    """Sobol' needs only per-rank partial sums -> one all-reduce of O(d n_qoi) doubles.  Two ranks
+    (gloo collectives, both on this box's one GPU) each evaluate half of the base samples; every rank ends with the
+    indices of the single-process run (sums are reassociated across ranks: equal to rounding)."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    n_base = 20_001
+    mp.spawn(_sobol_rank, args=(2, port, n_base, str(tmp_path)), nprocs=2, join=True)
+    one = drivers.sobol_indices(n_base, seed=5, fixed={'P_b': 1e-5, 'V_a': 300.0, 'mdot_a': 5e-6}, batch_size=4096)
+    for r in range(2):
+        got = np.load(tmp_path / f'rank{r}.npz')
+        for a in ('S1', 'ST'):
+            for k, v in one[a].items():
+                assert np.allclose(got[f'{a}_{k}'], v.cpu().numpy(), rtol=1e-9, atol=1e-12), (r, a, k)
