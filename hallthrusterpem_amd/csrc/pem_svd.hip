@@ -57,35 +57,40 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-// LDS: basis_p[ksteps*4][16] (zero padded) | per wave: tile[16*dof] + 4 zeroed slack doubles
-// UN = 16-byte pieces per lane of one 16-sample tile (ceil(8*dof/64)); the pieces of the NEXT tile are loaded into
+// A wave owns ROWS consecutive samples per tile (16 for dof <= 96; 8 above, so that the tile, the two prefetched tiles in
+// registers and the occupancy stay what they are for the 91-point profile: with 16 x 202 values the kernel needed ~400
+// registers and 26 KB of LDS per wave, one wave per SIMD, and ran at 1.8 TB/s); lane = (row, k-group), KG = 64 / ROWS
+// interleaved k-slices.
+// LDS: basis_p[ksteps*KG][16] (zero padded) | per wave: tile[ROWS*dof] + KG zeroed slack doubles
+// UN = 16-byte pieces per lane of one tile (ceil(ROWS*dof/2/64)); the pieces of the NEXT tile are loaded into
 // registers while the current tile is multiplied.  RT = latent columns computed (>= rank, zero-padded basis).
 // Index arithmetic is kept 32-bit and out of the inner loops: the first version spent 1740 VALU instructions per
 // 16-sample tile, most of them 64-bit address math (rocprofv3 SQ_INSTS_VALU), and ran at 2.3 TB/s.
-template <int UN, int RT, int MODE>
+template <int ROWS, int UN, int RT, int MODE>
 __global__ __launch_bounds__(BLOCK) void svd_compress_kernel(long long n, int dof, int r, double scale,
                                                              const double* __restrict__ field,
                                                              const double* __restrict__ basis,
                                                              double* __restrict__ latent) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* lds = reinterpret_cast<double*>(smem_raw);
-    const int ksteps = (dof + 3) / 4;
-    double* basis_p = lds;                                   // [ksteps*4][16]
-    const int tile_doubles = (16 * dof + 5) & ~1;
+    constexpr int KG = 64 / ROWS;                            // k-groups: lane (row, grp) takes k = grp, grp + KG, ...
+    const int ksteps = (dof + KG - 1) / KG;
+    double* basis_p = lds;                                   // [ksteps*KG][16]
+    const int tile_doubles = (ROWS * dof + KG + 1) & ~1;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    double* tile = lds + ksteps * 64 + wave * tile_doubles;  // [16][dof] + slack
-    for (int i = tid; i < ksteps * 64; i += BLOCK) {
+    double* tile = lds + ksteps * KG * 16 + wave * tile_doubles;  // [ROWS][dof] + slack
+    for (int i = tid; i < ksteps * KG * 16; i += BLOCK) {
         const int k = i >> 4, c = i & 15;
         basis_p[i] = (k < dof && c < r) ? basis[(size_t)k * r + c] : 0.0;
     }
-    if (lane < 4) tile[16 * dof + lane] = 0.0;               // read (times a zero basis row) by the last k-step
+    if (lane < KG) tile[ROWS * dof + lane] = 0.0;            // read (and masked) by the last k-step
     __syncthreads();
 
-    const int row = lane & 15, quad = lane >> 4;
-    const int tile_len = 16 * dof;                            // doubles per full tile
-    const long long ntiles = (n + 15) / 16;
+    const int row = lane & (ROWS - 1), quad = lane / ROWS;    // `quad` = k-group index (0..KG-1)
+    const int tile_len = ROWS * dof;                          // doubles per full tile
+    const long long ntiles = (n + ROWS - 1) / ROWS;
     const long long stride = (long long)gridDim.x * WAVES;
-    const bool vec_ok = (((uintptr_t)field) & 15) == 0;       // tiles start at multiples of 16*dof*8 bytes
+    const bool vec_ok = (((uintptr_t)field) & 15) == 0;       // tiles start at multiples of ROWS*dof*8 bytes
 
     // `len` = doubles of the tile that exist (tile_len except for the last tile of the batch)
     auto fetch = [&](const double* tp, int len, f64x2 (&v)[UN]) {
@@ -101,7 +106,7 @@ __global__ __launch_bounds__(BLOCK) void svd_compress_kernel(long long n, int do
         }
     };
     auto tile_length = [&](long long t) {
-        const long long rest = (n - t * 16) * dof;
+        const long long rest = (n - t * ROWS) * dof;
         return rest < tile_len ? (int)rest : tile_len;
     };
 
@@ -141,18 +146,18 @@ __global__ __launch_bounds__(BLOCK) void svd_compress_kernel(long long n, int do
 #pragma unroll 4
         for (int step = 0; step < ksteps - 1; ++step) {
             const double a = *ap;
-            ap += 4;
+            ap += KG;
 #pragma unroll
             for (int j = 0; j < RT; j += 2) {
                 const f64x2 b = bp[j >> 1];
                 acc[j] = fma(a, b.x, acc[j]);
                 if (j + 1 < RT) acc[j + 1] = fma(a, b.y, acc[j + 1]);
             }
-            bp += 32;                         // 4 basis rows of 16 doubles
+            bp += KG * 8;                     // KG basis rows of 16 doubles
         }
         {   // last step: k >= dof would read the next sample's first values (or slack) against a zero basis row --
             // masked, because 0 * inf = NaN would let one sample's non-finite value poison its neighbour's latents
-            const double a = quad + 4 * (ksteps - 1) < dof ? *ap : 0.0;
+            const double a = quad + KG * (ksteps - 1) < dof ? *ap : 0.0;
 #pragma unroll
             for (int j = 0; j < RT; j += 2) {
                 const f64x2 b = bp[j >> 1];
@@ -162,18 +167,18 @@ __global__ __launch_bounds__(BLOCK) void svd_compress_kernel(long long n, int do
         }
 #pragma unroll
         for (int j = 0; j < RT; ++j) {
-            acc[j] += __shfl_xor(acc[j], 16);
-            acc[j] += __shfl_xor(acc[j], 32);
+#pragma unroll
+            for (int sh = ROWS; sh < 64; sh <<= 1) acc[j] += __shfl_xor(acc[j], sh);
         }
-        // every quad now holds the full sums.  The tile's 16 x r latents are one contiguous block of `latent`:
+        // every k-group now holds the full sums.  The tile's ROWS x r latents are one contiguous block of `latent`:
         // gather them in LDS (the tile is consumed) and store them with consecutive lanes.
         wave_lds_sync();
 #pragma unroll
         for (int j = 0; j < RT; ++j)
-            if ((j & 3) == quad && j < r) tile[row * r + j] = acc[j];
+            if ((j & (KG - 1)) == quad && j < r) tile[row * r + j] = acc[j];
         wave_lds_sync();
         {
-            double* out = latent + t * 16 * r;
+            double* out = latent + t * ROWS * r;
             const int count = (len / dof) * r;
             for (int e = lane; e < count; e += 64) out[e] = tile[e];
         }
@@ -270,27 +275,32 @@ int pem_svd_compress_f64_dev(size_t n, int dof, int rank, int norm, double norm_
     if (int rc = check_args("pem_svd_compress", n, dof, rank, norm, field, basis, latent)) return rc;
     if (n == 0) return PEM_OK;
     if (int rc = pem::check_device()) return rc;
-    const size_t lds = ((size_t)((dof + 3) / 4) * 64 + (size_t)WAVES * ((16 * dof + 5) & ~1)) * 8;
-    // UN: 16-byte pieces per lane of a 16-sample tile (12 covers dof <= 96); RT: latent columns computed (>= rank)
-#define PEM_SVD_LAUNCH(UN_, RT_, MODE_)                                                                              \
+    // ROWS samples per tile: 16 (4 k-groups) for dof <= 96, 8 (8 k-groups) above; UN: 16-byte pieces per lane of a tile
+    // (12 covers 16 x 96, 13 covers 8 x 208); RT: latent columns computed (>= rank)
+    const int rows = dof <= 96 ? 16 : 8, kg = 64 / rows;
+    const size_t lds = ((size_t)((dof + kg - 1) / kg) * kg * 16 + (size_t)WAVES * ((rows * dof + kg + 1) & ~1)) * 8;
+    const size_t tiles = (n + rows - 1) / rows;
+    size_t blocks = (tiles + WAVES - 1) / WAVES;
+    if (blocks > 256 * 2) blocks = 256 * 2;
+#define PEM_SVD_LAUNCH(ROWS_, UN_, RT_, MODE_)                                                                            \
     do {                                                                                                             \
-        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(svd_compress_kernel<UN_, RT_, MODE_>), \
+        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(svd_compress_kernel<ROWS_, UN_, RT_, MODE_>), \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);        \
         HIP_TRY(attr);                                                                                               \
-        hipLaunchKernelGGL((svd_compress_kernel<UN_, RT_, MODE_>), dim3(grid_for(n)), dim3(BLOCK), lds,              \
+        hipLaunchKernelGGL((svd_compress_kernel<ROWS_, UN_, RT_, MODE_>), dim3((unsigned)blocks), dim3(BLOCK), lds, \
                            static_cast<hipStream_t>(stream), (long long)n, dof, rank, norm_scale, field, basis, latent); \
     } while (0)
-#define PEM_SVD_BY_MODE(UN_, RT_)                                                   \
+#define PEM_SVD_BY_MODE(ROWS_, UN_, RT_)                                                 \
     do {                                                                            \
-        if (norm == PEM_NORM_LOG10) PEM_SVD_LAUNCH(UN_, RT_, PEM_NORM_LOG10);       \
-        else if (norm == PEM_NORM_LINEAR) PEM_SVD_LAUNCH(UN_, RT_, PEM_NORM_LINEAR); \
-        else PEM_SVD_LAUNCH(UN_, RT_, PEM_NORM_NONE);                                \
+        if (norm == PEM_NORM_LOG10) PEM_SVD_LAUNCH(ROWS_, UN_, RT_, PEM_NORM_LOG10);       \
+        else if (norm == PEM_NORM_LINEAR) PEM_SVD_LAUNCH(ROWS_, UN_, RT_, PEM_NORM_LINEAR); \
+        else PEM_SVD_LAUNCH(ROWS_, UN_, RT_, PEM_NORM_NONE);                                \
     } while (0)
     const int rt = rank <= 4 ? 4 : (rank <= 8 ? 8 : 16);
     if (dof <= 96) {
-        if (rt == 4) PEM_SVD_BY_MODE(12, 4); else if (rt == 8) PEM_SVD_BY_MODE(12, 8); else PEM_SVD_BY_MODE(12, 16);
+        if (rt == 4) PEM_SVD_BY_MODE(16, 12, 4); else if (rt == 8) PEM_SVD_BY_MODE(16, 12, 8); else PEM_SVD_BY_MODE(16, 12, 16);
     } else {
-        if (rt == 4) PEM_SVD_BY_MODE(26, 4); else if (rt == 8) PEM_SVD_BY_MODE(26, 8); else PEM_SVD_BY_MODE(26, 16);
+        if (rt == 4) PEM_SVD_BY_MODE(8, 13, 4); else if (rt == 8) PEM_SVD_BY_MODE(8, 13, 8); else PEM_SVD_BY_MODE(8, 13, 16);
     }
 #undef PEM_SVD_BY_MODE
 #undef PEM_SVD_LAUNCH
