@@ -335,6 +335,36 @@ struct WaveLds {
     double* tile;            // [S*91] + 2
 };
 
+// The slow, literal evaluation of one lane's chunk of angles: direct exp() of -(alpha_k / alpha)^2 per beam, every
+// product and sum rounded separately, as plume.py:99-102 (and the oracle) do.  The recurrence of the angle loop is
+// accurate to ~1e-14 relative -- also where the reference's own exp() has run into the denormal range (argument
+// below -708) or rounded to zero (below -745.13), which is where "accurate" and "equal to the reference" part ways:
+// with j_cex = 0 the reference sees j_ion = 0 there and flags the sample invalid (plume.py:105).  A chunk whose
+// smallest value is below 1e-290 (or <= 0) is therefore recomputed this way; under the PEM-v0 priors j_cex > 1e-6
+// and this never runs.  Out of line: it must not cost the angle loop registers.
+struct ChunkSums {
+    double den, num, lo;
+};
+template <typename JT, bool WRITE_J>
+__device__ __attribute__((noinline)) ChunkSums exact_chunk(double X1a, double X2a, double jcex, double a1, double a2, int k0,
+                                                           int nk, const double2* w, JT* tile_row) {
+#pragma clang fp contract(off)
+    ChunkSums r{0.0, 0.0, __builtin_inf()};
+    for (int j = 0; j < nk; ++j) {
+        const int k = k0 + j;
+        if (k >= NANG) break;
+        const double alpha = k == NANG - 1 ? HALF_PI : (double)k * GRID_H;   // np.linspace(0, pi/2, 91)
+        const double t1 = alpha / a1, t2 = alpha / a2;
+        const double f = X1a * exp(-(t1 * t1)) + X2a * exp(-(t2 * t2));
+        const double ji = f + jcex;
+        if (WRITE_J) tile_row[j] = (JT)ji;
+        r.lo = fmin(r.lo, WRITE_J ? ji : f);
+        r.den = __builtin_fma(w[j].x, f, r.den);
+        r.num = __builtin_fma(w[j].y, f, r.num);
+    }
+    return r;
+}
+
 // The two divergence integrals as functions of one beam width (tools/gen_tables.py, QPOLY): with
 // f_k = X1 e_k(a1) + X2 e_k(a2) the Simpson sums of plume.py:117-123 are X1 Qd(a1) + X2 Qd(a2) and X1 Qn(a1) + X2 Qn(a2).
 // Region A: |a| >= 0.25, row floor(2u), u = 1/a^2;  region B: QA_MIN <= |a| < 0.25, row NDI + floor(t),
@@ -416,12 +446,16 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
     // amplitudes and depend on each beam only through its width -> two table look-ups per beam (simpson_functionals).
     // What the loop would still decide is plume.py:105's `any(j_ion <= 0)`; with both amplitudes >= 0 and j_cex > 0 every
     // j_ion[k] >= j_cex > 0, so the flag is `alpha1 <= 0` alone.  Such a "plain" sample takes its sums from the tables,
-    // any other one (NaN amplitudes, negative c0 or 1 - c0, beams narrower than QA_MIN) from the loop: a sample's result
+    // any other one (NaN or denormal amplitudes, negative c0 or 1 - c0, beams narrower than QA_MIN) from the loop: a sample's result
     // depends on that sample alone, however batches and shards cut the design.  The loop is skipped -- a wave-uniform
     // branch -- when all 64 samples of the tile are plain, which under the PEM-v0 priors is every tile.
     bool plain = false, table_tile = false;
     if constexpr (JMODE == 0) {
-        plain = fabs(a1) >= PEM_QA_MIN && fabs(a2) >= PEM_QA_MIN && base * A1 >= 0.0 && base * A2 >= 0.0 && j_cex > 0.0;
+        // (amplitudes in the denormal range are left to the loop as well: there every w_k f_k underflows to zero and the
+        // reference's 0/0 = NaN must come out, where the tabulated sum would still see a few bits)
+        const double X1a = base * A1, X2a = base * A2;
+        plain = fabs(a1) >= PEM_QA_MIN && fabs(a2) >= PEM_QA_MIN && X1a >= 0.0 && X2a >= 0.0 && j_cex > 0.0 &&
+                (fmax(X1a, X2a) >= 1e-280 || (X1a == 0.0 && X2a == 0.0));
         table_tile = __all(plain);
         if (table_tile) inv_mask = a1_nonpos;
     }
@@ -527,6 +561,24 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
                 rr1 *= q1;
                 X2 *= rr2;
                 rr2 *= q2;
+            }
+            if constexpr (!LATENT) {
+                // deep-underflow or non-positive chunk: the literal evaluation decides (see exact_chunk); rare, and the
+                // branch is wave-uniform so that the shuffles inside are executed by every lane
+                // (an infinite amplitude -- exp(+x) overflow for a negative density -- must turn into NaN where the
+                // reference's exp() is exactly zero.  A class test, not `X - X != 0`: hipcc contracts that with the
+                // multiply before it into fma(X', rr, -X), the rounding error of the product, which is never zero.)
+                const bool uncertain = (WRITE_J ? lo : lo + jcex) < 1e-290 || !__builtin_isfinite(X1) || !__builtin_isfinite(X2);
+                if (__ballot(uncertain)) {
+                    const double a1s = __shfl(a1, smp), a2s = __shfl(a2, smp);
+                    if (uncertain) {
+                        const ChunkSums ex = exact_chunk<JT, WRITE_J>(params[0 * WAVE + smp], params[1 * WAVE + smp], jcex, a1s,
+                                                                      a2s, k0, CH, my_w, tile + s * NANG + k0);
+                        den = ex.den;
+                        num = ex.num;
+                        lo = ex.lo;
+                    }
+                }
             }
             // this round has read its nine parameter rows of sample `smp`: rows 2c, 2c+1 now carry the partial sums
             params[(2 * c) * WAVE + smp] = den;
@@ -654,8 +706,16 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
     wave_lds_sync();  // params are rewritten by the next tile
 }
 
+// Minimum waves per SIMD the register allocator must leave room for: 1 (the default for a 4-wave workgroup; every
+// instantiation ends up at two anyway) except the fused Monte-Carlo reduced-QoI one, which is bound by Philox's
+// quarter-rate 32x32 multiplies and gains a third wave (99 -> 86 us per 1.25e6 samples); unconstrained it takes 171
+// registers, three more than three waves allow.
+template <int JMODE, bool MC>
+constexpr int min_waves_per_simd() { return (MC && JMODE == 0) ? 3 : 1; }
+
 template <int L, bool COUPLED, int JMODE, bool MC = false>
-__global__ __launch_bounds__(WAVE * WPB) void plume_r1_kernel(PlumeIO io, CoupledIO cio, long long ntiles, McDesign mc) {
+__global__ __launch_bounds__(WAVE * WPB) __attribute__((amdgpu_waves_per_eu(min_waves_per_simd<JMODE, MC>())))
+void plume_r1_kernel(PlumeIO io, CoupledIO cio, long long ntiles, McDesign mc) {
     static_assert(!MC || COUPLED, "the fused Monte-Carlo mode generates the coupled inputs");
     static_assert(L == 2 || L == 4 || L == 8, "lanes per sample");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -929,16 +989,13 @@ std::once_flag g_grid_once;
 using pem::check_device;
 using pem::fail;
 
-// persistent grid of the fast kernel: workgroups of WPB waves, as many as the LDS admits on every CU, capped at
-// two waves per SIMD
-int fast_grid(size_t lds_bytes, long long ntiles, unsigned* grid, int max_waves_per_cu = 8) {
+// persistent grid of the fast kernel: workgroups of WPB waves, `per_cu` of them resident on every CU
+int fast_grid(long long per_cu, long long ntiles, unsigned* grid) {
     static int cus[64] = {0};
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return fail(PEM_ERR_INVALID_ARG, "device index %d out of range", dev);
     if (cus[dev] == 0) HIP_TRY(hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev));
-    long long per_cu = (long long)(160 * 1024 / lds_bytes);   // workgroups per CU
-    if (per_cu > max_waves_per_cu / WPB) per_cu = max_waves_per_cu / WPB;
     if (const char* e = getenv("PEM_WAVES_PER_CU")) {          // tuning/experiments only
         const long long v = atoll(e) / WPB;
         if (v >= 1 && v < per_cu) per_cu = v;
@@ -959,15 +1016,32 @@ int launch_r1(const PlumeIO& io, const CoupledIO& cio, hipStream_t st, const McD
     if (JMODE == 0) lds += (size_t)QPOLY_DOUBLES * 8;
     const long long ntiles = (io.n + WAVE - 1) / WAVE;
     unsigned grid = 0;
-    // the fused Monte-Carlo reduced-QoI kernel needs 165 registers: three waves per SIMD help it hide Philox's
-    // quarter-rate multiplies; every other instantiation needs more than 170 and gets two
-    if (int rc = fast_grid(lds, ntiles, &grid, (MC && JMODE == 0) ? 12 : 8)) return rc;
     auto kern = plume_r1_kernel<L, COUPLED, JMODE, MC>;
     if (lds > 64 * 1024) {
         static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         HIP_TRY(attr);
     }
+    // Workgroups resident per CU: bounded by the LDS (160 KB) and by the registers this instantiation was compiled to
+    // (hipFuncGetAttributes; 512 per SIMD lane) -- the persistent loop must launch exactly as many as fit, a workgroup that
+    // waits for a slot turns the tile split into a two-pass schedule -- and capped at two waves per SIMD, which measured
+    // best for the HBM-bound modes, three for the profile-less ones: the fused Monte-Carlo kernel uses a third wave to
+    // hide Philox's quarter-rate multiplies whenever its register count allows one (<= 168).
+    static int by_regs = 0;
+    if (by_regs == 0) {
+        hipFuncAttributes fa;
+        HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern)));
+        const int regs = fa.numRegs > 0 ? ((fa.numRegs + 7) & ~7) : 256;
+        by_regs = (512 / regs) * 4 / WPB;
+        if (getenv("PEM_DEBUG_OCCUPANCY"))
+            fprintf(stderr, "pem: plume_r1_kernel<%d,%d,%d,%d>: %d registers -> %d workgroups per CU\n", L, (int)COUPLED, JMODE,
+                    (int)MC, fa.numRegs, by_regs);
+    }
+    long long cached_per_cu = (long long)(160 * 1024 / lds);
+    const int cap = (JMODE == 0 ? 12 : 8) / WPB;
+    if (cached_per_cu > by_regs) cached_per_cu = by_regs;
+    if (cached_per_cu > cap) cached_per_cu = cap;
+    if (int rc = fast_grid(cached_per_cu, ntiles, &grid)) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * WPB), lds, st, io, cio, ntiles, mc);
     HIP_TRY(hipGetLastError());
     return PEM_OK;

@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""Differential fuzzing of the device path against the CPU oracle (test infrastructure) on inputs far outside the
+priors: signs, zeros, huge / tiny magnitudes, NaN / inf, beams around every table boundary.  For each seed the coupled
+evaluation runs in full, reduced and mixed mode and the plume alone with several radii; NaN / inf / invalid patterns
+must agree exactly, finite values to 1e-10 (div_angle by conftest.div_err's rule) wherever the quantity is defined by
+normal-range arithmetic:
+  * div_angle / T_c are ratios of two Simpson sums of the beam terms; when the beam amplitude I_B0 exp(-r n sigma) / r^2
+    is itself a denormal number (0 < |.| < 1e-280) both sums are a few denormal bits in the reference and here, and
+    their ratio is noise on both sides -- such samples are compared for NaN / inf pattern only; with c0 outside [0, 1]
+    one beam amplitude is negative and the two sums cancel -- those samples are held to 1e-6;
+  * V_cc = V_vac + T_e ln(1 + PB/PT) - T_e PB / (PT + P*) cancels for wild pressure ratios, j_cex carries the
+    rounding of 1 - exp(-x), and with a negative amplitude or a negative j_cex (c0 outside [0, 1], negative density or
+    cross-section) j_ion = j_beam + j_scat + j_cex cancels too: the tolerance is 1e-10 of the value plus 1e-13 of the
+    largest term (for j_ion: of the largest entry of that sample's profile), not 1e-10 of the cancelled result.
+Prints the worst errors.
+
+    python tools/fuzz_parity.py [--seeds 40] [--n 20000]
+"""
+import argparse
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / 'tests'))
+
+
+def wild(rng, n):
+    def mix(base, *alts):
+        out = base.copy()
+        for frac, vals in alts:
+            m = rng.random(n) < frac
+            out[m] = vals[m] if isinstance(vals, np.ndarray) else vals
+        return out
+    u = rng.random((15, n))
+    sgn = np.where(rng.random(n) < 0.5, -1.0, 1.0)
+    x = {'P_b': mix(10 ** (u[0] * 6 - 9), (0.02, 0.0), (0.02, -1e-5), (0.01, np.inf), (0.01, 1e3)),
+         'V_a': mix(u[1] * 400 + 50, (0.02, 0.0), (0.02, -100.0)),
+         'T_e': mix(u[2] * 8, (0.02, 0.0), (0.01, -2.0)),
+         'V_vac': mix(u[3] * 120 - 30, (0.05, 0.0)),
+         'Pstar': mix(10 ** (u[4] * 4 - 7), (0.02, 0.0), (0.01, -1e-5)),
+         'P_T': mix(10 ** (u[5] * 4 - 7), (0.02, 0.0), (0.01, -1e-5)),
+         'mdot_a': mix(u[6] * 1e-5, (0.02, 0.0), (0.01, -1e-6)),
+         'a_1': mix(10 ** (u[7] * 3 - 3), (0.02, 0.5), (0.02, 0.2)),                      # eta_c = 1 - 2 a_1 = 0
+         'c0': mix(u[8] * 1.4 - 0.2, (0.03, 0.0), (0.03, 1.0)),
+         'c1': mix(u[9] * 1.2 - 0.1, (0.02, 0.0), (0.02, 1e-3), (0.01, -0.5)),
+         'c2': mix((u[10] * 2 - 1) * 10 ** (rng.random(n) * 4 - 1), (0.1, 0.0)),
+         # alpha1 around every switch of the kernel: 0, QA_MIN = 0.03, 0.25, pi/2 clip, and alpha2 = alpha1 / c1 up to the
+         # erfi-overflow bound 53.28
+         'c3': mix(10 ** (u[11] * 3.5 - 2.5) * np.where(rng.random(n) < 0.05, -1, 1), (0.02, 0.0), (0.03, 0.03), (0.03, 0.25),
+                   (0.03, 0.0299999), (0.03, 0.2500001), (0.02, 1.5707963267948966), (0.02, 53.28349511409265 * 1e-3)),
+         'c4': mix(10 ** (u[12] * 8 + 16), (0.02, 0.0), (0.01, -1e19)),
+         'c5': mix(10 ** (u[13] * 8 + 10), (0.02, 0.0), (0.01, -1e15)),
+         'sigma_cex': mix(u[14] * 1e-18, (0.02, 0.0), (0.01, -5e-19))}
+    for k in x:
+        m = rng.random(n) < 0.002
+        x[k][m] = np.nan
+    x['c3'] *= np.where(rng.random(n) < 0.02, sgn, 1.0)
+    return x
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--seeds', type=int, default=40)
+    ap.add_argument('--n', type=int, default=20_000)
+    args = ap.parse_args()
+    import torch
+    from conftest import div_err, rel_err
+    from oracle import oracle_ctypes as oc
+    from hallthrusterpem_amd import constants
+    from hallthrusterpem_amd.batch import CoupledBatch
+    from hallthrusterpem_amd.models import current_density, pem_v0_coupled
+    oc.set_threads(16)
+    worst = {}
+
+    def note(key, val):
+        worst[key] = max(worst.get(key, 0.0), float(val))
+
+    def same_pattern(a, b, what):
+        assert np.array_equal(np.isnan(a), np.isnan(b)), f'NaN pattern differs: {what}'
+        assert np.array_equal(np.isinf(a), np.isinf(b)) and np.array_equal(np.sign(a[np.isinf(a)]), np.sign(b[np.isinf(b)])), f'inf pattern differs: {what}'
+
+    for seed in range(args.seeds):
+        rng = np.random.default_rng(1000 + seed)
+        x = wild(rng, args.n)
+        with np.errstate(all='ignore'):
+            want = oc.coupled(x, constants.TORR_2_PA)
+        full = pem_v0_coupled(x)
+        red = pem_v0_coupled(x, profile=False)
+        with np.errstate(all='ignore'):
+            k = constants.TORR_2_PA
+            base = want['I_B0'] * np.exp(-(x['c4'] * (x['P_b'] * k) + x['c5']) * x['sigma_cex'])      # radius 1 m
+            beams_normal = ~((np.abs(base) < 1e-280) & (base != 0.0))
+            same_sign = (x['c0'] >= 0.0) & (x['c0'] <= 1.0)
+            lg = np.log(1.0 + x['P_b'] * k / (x['P_T'] * k))
+            v_scale = np.abs(x['V_vac']) + np.abs(x['T_e'] * lg) + np.abs(x['T_e'] / ((x['P_T'] + x['Pstar']) * k) * (x['P_b'] * k))
+            j_floor = 8 * np.finfo(float).eps * np.abs(want['I_B0']) / (2 * np.pi)                   # rounding of 1 - decay
+        for name, got in (('full', full), ('reduced', red)):
+            assert np.array_equal(got['invalid'], want['invalid']), f'invalid flags differ ({name}, seed {seed})'
+            for key in ('V_cc', 'I_B0', 'T', 'T_c', 'div_angle') + (('j_ion',) if name == 'full' else ()):
+                g, w = np.asarray(got[key]).reshape(-1), np.asarray(want[key]).reshape(-1)
+                same_pattern(g, w, f'{key} ({name}, seed {seed})')
+                if key in ('div_angle', 'T_c'):
+                    for tag, m in (('', beams_normal & same_sign), (' (beams of opposite sign)', beams_normal & ~same_sign)):
+                        note(f'{name}.{key}{tag}', div_err(g[m], w[m]) if key == 'div_angle' else rel_err(g[m], w[m]))
+                elif key == 'V_cc':
+                    fin = np.isfinite(w) & np.isfinite(v_scale)
+                    note(f'{name}.{key}', np.max(np.abs(g[fin] - w[fin]) / np.maximum(np.abs(w[fin]), v_scale[fin]), initial=0.0))
+                elif key == 'j_ion':
+                    with np.errstate(all='ignore'):
+                        peak = np.nanmax(np.abs(np.where(np.isfinite(w), w, np.nan)).reshape(-1, 91), axis=1)
+                    fl = np.repeat(j_floor + 1e-13 * np.nan_to_num(peak), 91)
+                    fin = np.isfinite(w) & np.isfinite(fl)
+                    note(f'{name}.{key}', np.max(np.abs(g[fin] - w[fin]) / (np.abs(w[fin]) + 1e10 * fl[fin] + 1e-300), initial=0.0))
+                else:
+                    note(f'{name}.{key}', rel_err(g, w))
+        b = CoupledBatch(args.n, mixed=True)
+        b.set_inputs(x)
+        b.run()
+        torch.cuda.synchronize()
+        j32 = b.j_ion.cpu().numpy().astype(np.float64).reshape(-1)
+        j64 = np.asarray(full['j_ion']).reshape(-1).astype(np.float32).astype(np.float64)
+        assert np.array_equal(j32, j64, equal_nan=True), f'mixed profile is not the rounded fp64 profile (seed {seed})'
+        # plume alone, several radii (generic kernel) and one radius (fast path)
+        p = {k: x[k] for k in ('P_b', 'c0', 'c1', 'c2', 'c3', 'c4', 'c5', 'sigma_cex')}
+        p['I_B0'], p['T'] = full['I_B0'], full['T']
+        for radii in ((1.0,), (0.5, 1.0, 2.5)):
+            with np.errstate(all='ignore'):
+                w = oc.plume(p['P_b'], p['c0'], p['c1'], p['c2'], p['c3'], p['c4'], p['c5'], p['sigma_cex'], p['I_B0'],
+                             constants.TORR_2_PA, T=p['T'], radii=radii)
+            g = current_density(p, sweep_radius=radii[0] if len(radii) == 1 else np.array(radii))
+            with np.errstate(all='ignore'):
+                rr = np.asarray(radii)
+                nsig = (x['c4'] * (x['P_b'] * constants.TORR_2_PA) + x['c5']) * x['sigma_cex']
+                bR = p['I_B0'][:, None] * np.exp(-rr[None, :] * nsig[:, None]) / rr[None, :] ** 2
+                okR = ~((np.abs(bR) < 1e-280) & (bR != 0.0))                                         # (n, R)
+                flR = 8 * np.finfo(float).eps * np.abs(p['I_B0'])[:, None] / (2 * np.pi * rr[None, :] ** 2)
+            for key in ('j_ion', 'div_angle', 'T_c'):
+                gg, ww = np.asarray(g[key]).reshape(-1), np.asarray(w[key]).reshape(-1)
+                same_pattern(gg, ww, f'plume {key} R={len(radii)} seed {seed}')
+                if key == 'j_ion':
+                    with np.errstate(all='ignore'):
+                        w3 = np.where(np.isfinite(ww), np.abs(ww), np.nan).reshape(args.n, 91, len(radii))
+                        peak = np.nan_to_num(np.nanmax(w3, axis=1))                                  # (n, R)
+                    fl = np.broadcast_to((flR + 1e-13 * peak)[:, None, :], (args.n, 91, len(radii))).reshape(-1)
+                    fin = np.isfinite(ww) & np.isfinite(fl)
+                    note(f'plume[R={len(radii)}].{key}', np.max(np.abs(gg[fin] - ww[fin]) / (np.abs(ww[fin]) + 1e10 * fl[fin] + 1e-300), initial=0.0))
+                else:
+                    for tag, ss in (('', same_sign), (' (beams of opposite sign)', ~same_sign)):
+                        m = (okR & ss[:, None]).reshape(-1)
+                        note(f'plume[R={len(radii)}].{key}{tag}', div_err(gg[m], ww[m]) if key == 'div_angle' else rel_err(gg[m], ww[m]))
+    print(f'{args.seeds} seeds x {args.n} wild samples: NaN / inf / invalid patterns identical everywhere; worst errors:')
+    for k, v in sorted(worst.items()):
+        print(f'  {k:28s} {v:.2e}')
+    # the multi-radius kernel (not a BASELINE configuration) runs one 91-step recurrence per beam instead of four chunks of
+    # 23: its Gaussians carry up to 91^2/2 ulp = 5e-13 relative, which arccos and the cancelling cases above amplify
+    for key, v in worst.items():
+        tol = 1e-6 if 'opposite sign' in key else (1e-9 if key.startswith('plume[R=3]') else 1e-10)
+        assert v <= tol, f'tolerance exceeded: {key} {v:.2e}'
+
+
+if __name__ == '__main__':
+    main()
