@@ -365,6 +365,27 @@ __device__ __attribute__((noinline)) ChunkSums exact_chunk(double X1a, double X2
     return r;
 }
 
+// The fused-compression mode's share of the same literal re-evaluation: the chunk's contribution to the latents.
+struct LatSums {
+    double v[8];
+};
+__device__ __attribute__((noinline)) LatSums exact_latents(double X1a, double X2a, double jcex, double a1, double a2, int k0,
+                                                           int nk, const double* basis_rows, int log_norm) {
+#pragma clang fp contract(off)
+    LatSums r;
+    for (int q = 0; q < 8; ++q) r.v[q] = 0.0;
+    for (int j = 0; j < nk; ++j) {
+        const int k = k0 + j;
+        if (k >= NANG) break;
+        const double alpha = k == NANG - 1 ? HALF_PI : (double)k * GRID_H;
+        const double t1 = alpha / a1, t2 = alpha / a2;
+        const double ji = (X1a * exp(-(t1 * t1)) + X2a * exp(-(t2 * t2))) + jcex;
+        const double lj = log_norm ? pem::pem_log10(ji) : ji;
+        for (int q = 0; q < 8; ++q) r.v[q] = __builtin_fma(lj, basis_rows[j * 8 + q], r.v[q]);
+    }
+    return r;
+}
+
 // The two divergence integrals as functions of one beam width (tools/gen_tables.py, QPOLY): with
 // f_k = X1 e_k(a1) + X2 e_k(a2) the Simpson sums of plume.py:117-123 are X1 Qd(a1) + X2 Qd(a2) and X1 Qn(a1) + X2 Qn(a2).
 // Region A: |a| >= 0.25, row floor(2u), u = 1/a^2;  region B: QA_MIN <= |a| < 0.25, row NDI + floor(t),
@@ -562,7 +583,7 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
                 X2 *= rr2;
                 rr2 *= q2;
             }
-            if constexpr (!LATENT) {
+            {
                 // deep-underflow or non-positive chunk: the literal evaluation decides (see exact_chunk); rare, and the
                 // branch is wave-uniform so that the shuffles inside are executed by every lane
                 // (an infinite amplitude -- exp(+x) overflow for a negative density -- must turn into NaN where the
@@ -572,11 +593,17 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
                 if (__ballot(uncertain)) {
                     const double a1s = __shfl(a1, smp), a2s = __shfl(a2, smp);
                     if (uncertain) {
-                        const ChunkSums ex = exact_chunk<JT, WRITE_J>(params[0 * WAVE + smp], params[1 * WAVE + smp], jcex, a1s,
-                                                                      a2s, k0, CH, my_w, tile + s * NANG + k0);
+                        const double X1a = params[0 * WAVE + smp], X2a = params[1 * WAVE + smp];
+                        const ChunkSums ex = exact_chunk<JT, WRITE_J>(X1a, X2a, jcex, a1s, a2s, k0, CH, my_w, tile + s * NANG + k0);
                         den = ex.den;
                         num = ex.num;
                         lo = ex.lo;
+                        if constexpr (LATENT) {
+                            static_assert(LAT_RT == 8, "LatSums carries eight latent columns");
+                            const LatSums el = exact_latents(X1a, X2a, jcex, a1s, a2s, k0, CH, m.basis + k0 * LAT_RT, io.log_norm);
+#pragma unroll
+                            for (int r = 0; r < LAT_RT; ++r) lat[r] = el.v[r];
+                        }
                     }
                 }
             }

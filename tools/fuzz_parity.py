@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Differential fuzzing of the device path against the CPU oracle (test infrastructure) on inputs far outside the
 priors: signs, zeros, huge / tiny magnitudes, NaN / inf, beams around every table boundary.  For each seed the coupled
-evaluation runs in full, reduced and mixed mode and the plume alone with several radii; NaN / inf / invalid patterns
+evaluation runs in full, reduced and mixed mode, fused with the likelihood and with the SVD compression (against their
+two-launch pipelines), and the plume alone with several radii; NaN / inf / invalid patterns
 must agree exactly, finite values to 1e-10 (div_angle by conftest.div_err's rule) wherever the quantity is defined by
 normal-range arithmetic:
   * div_angle / T_c are ratios of two Simpson sums of the beam terms; when the beam amplitude I_B0 exp(-r n sigma) / r^2
@@ -74,6 +75,15 @@ def main():
     from hallthrusterpem_amd.models import current_density, pem_v0_coupled
     oc.set_threads(16)
     worst = {}
+    from hallthrusterpem_amd.compression import SVDCompression
+    from hallthrusterpem_amd.likelihood import JionLikelihood
+    frng = np.random.default_rng(7)
+    alpha = np.sort(frng.uniform(-np.pi / 2, np.pi / 2, (7, 29)), axis=1)
+    alpha[0, 0], alpha[0, -1] = -np.pi / 2, np.pi / 2
+    yv = frng.lognormal(0.0, 2.0, (7, 29))
+    lik = JionLikelihood(alpha, yv, 0.3 * yv + 0.01)
+    comp = SVDCompression(norm='log10', rank=6)
+    comp.basis = torch.from_numpy(np.ascontiguousarray(np.linalg.qr(frng.standard_normal((91, 6)))[0])).cuda()
 
     def note(key, val):
         worst[key] = max(worst.get(key, 0.0), float(val))
@@ -123,6 +133,26 @@ def main():
         j32 = b.j_ion.cpu().numpy().astype(np.float64).reshape(-1)
         j64 = np.asarray(full['j_ion']).reshape(-1).astype(np.float32).astype(np.float64)
         assert np.array_equal(j32, j64, equal_nan=True), f'mixed profile is not the rounded fp64 profile (seed {seed})'
+        # the fused modes against their two-launch pipelines on the same wild inputs: likelihood and SVD compression
+        ref = CoupledBatch(args.n, profile=True, thruster_qoi=False)
+        ref.set_inputs(x)
+        ref.run()
+        fused = CoupledBatch(args.n, profile=False, thruster_qoi=False)
+        fused.inputs.copy_(ref.inputs)
+        want_ll = lik.per_sample(ref.j_ion).cpu().numpy()
+        got_ll = fused.run_loglik(lik).cpu().numpy()
+        assert torch.equal(fused.invalid, ref.invalid), f'invalid flags differ (fused likelihood, seed {seed})'
+        same_pattern(got_ll, want_ll, f'fused loglik (seed {seed})')
+        fin = np.isfinite(want_ll)
+        note('fused.loglik', np.max(np.abs(got_ll[fin] - want_ll[fin]) / np.maximum(np.abs(want_ll[fin]), 1.0), initial=0.0))
+        want_z = comp.compress(ref.j_ion).cpu().numpy()
+        got_z = fused.run_latent(comp).cpu().numpy()
+        assert torch.equal(fused.invalid, ref.invalid), f'invalid flags differ (fused compression, seed {seed})'
+        same_pattern(got_z, want_z, f'fused latents (seed {seed})')
+        with np.errstate(all='ignore'):
+            scale = np.nansum(np.abs(np.log10(np.abs(ref.j_ion.cpu().numpy()))), axis=1, keepdims=True)   # sum_k |log10 j_k|
+        fin = np.isfinite(want_z) & np.isfinite(scale)
+        note('fused.latent', np.max((np.abs(got_z - want_z) / np.maximum(scale, 1.0))[fin], initial=0.0))
         # plume alone, several radii (generic kernel) and one radius (fast path)
         p = {k: x[k] for k in ('P_b', 'c0', 'c1', 'c2', 'c3', 'c4', 'c5', 'sigma_cex')}
         p['I_B0'], p['T'] = full['I_B0'], full['T']
@@ -157,7 +187,7 @@ def main():
     # the multi-radius kernel (not a BASELINE configuration) runs one 91-step recurrence per beam instead of four chunks of
     # 23: its Gaussians carry up to 91^2/2 ulp = 5e-13 relative, which arccos and the cancelling cases above amplify
     for key, v in worst.items():
-        tol = 1e-6 if 'opposite sign' in key else (1e-9 if key.startswith('plume[R=3]') else 1e-10)
+        tol = 1e-6 if 'opposite sign' in key else (1e-9 if key.startswith(('plume[R=3]', 'fused.')) else 1e-10)
         assert v <= tol, f'tolerance exceeded: {key} {v:.2e}'
 
 
