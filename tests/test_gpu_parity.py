@@ -91,6 +91,21 @@ def test_plume_golden(pem, name):
         assert np.sqrt(np.sum((cur - cur.mean()) ** 2) / np.sum(cur ** 2)) < 1e-4
 
 
+def test_plume_fuzz_golden(pem):
+    """The reference's outputs on 1560 fuzzed samples (tests/golden/plume_fuzz.npz), incl. the deep-underflow regimes:
+    exp() flushed to zero in a narrow beam's tail, denormal and infinite amplitudes."""
+    from conftest import wild_plume_errors
+    from hallthrusterpem_amd.models import current_density
+    g = load_golden('plume_fuzz')
+    k = float(g['TORR_2_PA'])
+    pem.constants.set_torr_2_pa(k)
+    inputs = {q[3:]: g[q] for q in g if q.startswith('in_')}
+    out = current_density(inputs, sweep_radius=1.0)
+    want = {q: g['out_' + q] for q in ('j_ion', 'div_angle', 'T_c')}
+    err = wild_plume_errors(inputs, out, want, k)
+    assert err['compared'] > 500 and err['j_ion'] <= RTOL and err['div_angle'] <= RTOL and err['T_c'] <= RTOL
+
+
 def test_plume_shapes_golden(pem):
     from hallthrusterpem_amd.models import current_density
     g = load_golden('plume_shapes')

@@ -73,6 +73,23 @@ def test_plume_against_reference(name):
         assert j.shape == (96, 91, 5) and j.min() >= 0 and j.max() <= 5e3
 
 
+def test_plume_against_reference_on_fuzzed_inputs():
+    """tests/golden/plume_fuzz.npz: 1560 samples far outside the priors with the reference's outputs, among them the
+    deep-underflow regimes differential fuzzing found (tests/golden/fuzz_reference.py held the oracle to the reference on
+    1.2e6 such samples when the fixture was written)."""
+    from conftest import wild_plume_errors
+    g = load_golden('plume_fuzz')
+    k = float(g['TORR_2_PA'])
+    out = oc.plume(*_plume_inputs(g), k, T=g['in_T'], radii=g['radii'])
+    got = {'j_ion': out['j_ion'][:, :, 0], 'div_angle': out['div_angle'][:, 0], 'T_c': out['T_c'][:, 0]}
+    want = {q: g['out_' + q] for q in ('j_ion', 'div_angle', 'T_c')}
+    inputs = {q[3:]: g[q] for q in g if q.startswith('in_')}
+    err = wild_plume_errors(inputs, got, want, k)
+    assert err['compared'] > 500 and err['j_ion'] <= 1e-10 and err['div_angle'] <= 1e-10 and err['T_c'] <= 1e-10
+    nan_rows, inv_rows = np.isnan(want['j_ion']).any(axis=1).sum(), np.all(want['j_ion'] == 1e-20, axis=1).sum()
+    assert nan_rows > 50 and inv_rows > 200                       # the fixture does contain the special regimes
+
+
 def test_plume_edge_semantics():
     """SURVEY.md Appendix B items 6-8 as observed on the reference (rows of plume_edges)."""
     g = load_golden('plume_edges')

@@ -7,7 +7,9 @@ must agree exactly, finite values to 1e-10 (div_angle by conftest.div_err's rule
 normal-range arithmetic:
   * div_angle / T_c are ratios of two Simpson sums of the beam terms; when the beam amplitude I_B0 exp(-r n sigma) / r^2
     is itself a denormal number (0 < |.| < 1e-280) both sums are a few denormal bits in the reference and here, and
-    their ratio is noise on both sides -- such samples are compared for NaN / inf pattern only; with c0 outside [0, 1]
+    their ratio is noise on both sides -- such samples are compared for NaN / inf pattern only; when both beams are
+    narrower than a quarter of the 1-degree grid only the centreline point contributes, cos_div = 1 to the last bit and
+    arccos returns 0 or NaN depending on that bit -- div_angle of such samples is not compared; with c0 outside [0, 1]
     one beam amplitude is negative and the two sums cancel -- those samples are held to 1e-6;
   * V_cc = V_vac + T_e ln(1 + PB/PT) - T_e PB / (PT + P*) cancels for wild pressure ratios, j_cex carries the
     rounding of 1 - exp(-x), and with a negative amplitude or a negative j_cex (c0 outside [0, 1], negative density or
@@ -86,6 +88,7 @@ def main():
     comp.basis = torch.from_numpy(np.ascontiguousarray(np.linalg.qr(frng.standard_normal((91, 6)))[0])).cuda()
 
     def note(key, val):
+        assert val == val, f'{key}: the error metric itself is NaN'
         worst[key] = max(worst.get(key, 0.0), float(val))
 
     def same_pattern(a, b, what):
@@ -104,6 +107,9 @@ def main():
             base = want['I_B0'] * np.exp(-(x['c4'] * (x['P_b'] * k) + x['c5']) * x['sigma_cex'])      # radius 1 m
             beams_normal = ~((np.abs(base) < 1e-280) & (base != 0.0))
             same_sign = (x['c0'] >= 0.0) & (x['c0'] <= 1.0)
+            a1w = np.minimum(x['c2'] * (x['P_b'] * k) + x['c3'], np.pi / 2)
+            resolved = ~(np.maximum(np.abs(a1w), np.abs(a1w / x['c1'])) < 0.0044)
+            beams_normal &= resolved
             lg = np.log(1.0 + x['P_b'] * k / (x['P_T'] * k))
             v_scale = np.abs(x['V_vac']) + np.abs(x['T_e'] * lg) + np.abs(x['T_e'] / ((x['P_T'] + x['Pstar']) * k) * (x['P_b'] * k))
             j_floor = 8 * np.finfo(float).eps * np.abs(want['I_B0']) / (2 * np.pi)                   # rounding of 1 - decay
@@ -111,16 +117,19 @@ def main():
             assert np.array_equal(got['invalid'], want['invalid']), f'invalid flags differ ({name}, seed {seed})'
             for key in ('V_cc', 'I_B0', 'T', 'T_c', 'div_angle') + (('j_ion',) if name == 'full' else ()):
                 g, w = np.asarray(got[key]).reshape(-1), np.asarray(want[key]).reshape(-1)
-                same_pattern(g, w, f'{key} ({name}, seed {seed})')
+                if key == 'div_angle':
+                    same_pattern(g[resolved], w[resolved], f'{key} ({name}, seed {seed})')
+                else:
+                    same_pattern(g, w, f'{key} ({name}, seed {seed})')
                 if key in ('div_angle', 'T_c'):
                     for tag, m in (('', beams_normal & same_sign), (' (beams of opposite sign)', beams_normal & ~same_sign)):
                         note(f'{name}.{key}{tag}', div_err(g[m], w[m]) if key == 'div_angle' else rel_err(g[m], w[m]))
                 elif key == 'V_cc':
                     fin = np.isfinite(w) & np.isfinite(v_scale)
-                    note(f'{name}.{key}', np.max(np.abs(g[fin] - w[fin]) / np.maximum(np.abs(w[fin]), v_scale[fin]), initial=0.0))
+                    note(f'{name}.{key}', np.max(np.abs(g[fin] - w[fin]) / np.maximum(np.maximum(np.abs(w[fin]), v_scale[fin]), 1e-300), initial=0.0))
                 elif key == 'j_ion':
                     with np.errstate(all='ignore'):
-                        peak = np.nanmax(np.abs(np.where(np.isfinite(w), w, np.nan)).reshape(-1, 91), axis=1)
+                        peak = np.max(np.where(np.isfinite(w), np.abs(w), 0.0).reshape(-1, 91), axis=1)
                     fl = np.repeat(j_floor + 1e-13 * np.nan_to_num(peak), 91)
                     fin = np.isfinite(w) & np.isfinite(fl)
                     note(f'{name}.{key}', np.max(np.abs(g[fin] - w[fin]) / (np.abs(w[fin]) + 1e10 * fl[fin] + 1e-300), initial=0.0))
@@ -165,15 +174,19 @@ def main():
                 rr = np.asarray(radii)
                 nsig = (x['c4'] * (x['P_b'] * constants.TORR_2_PA) + x['c5']) * x['sigma_cex']
                 bR = p['I_B0'][:, None] * np.exp(-rr[None, :] * nsig[:, None]) / rr[None, :] ** 2
-                okR = ~((np.abs(bR) < 1e-280) & (bR != 0.0))                                         # (n, R)
+                okR = ~((np.abs(bR) < 1e-280) & (bR != 0.0)) & resolved[:, None]                     # (n, R)
                 flR = 8 * np.finfo(float).eps * np.abs(p['I_B0'])[:, None] / (2 * np.pi * rr[None, :] ** 2)
             for key in ('j_ion', 'div_angle', 'T_c'):
                 gg, ww = np.asarray(g[key]).reshape(-1), np.asarray(w[key]).reshape(-1)
-                same_pattern(gg, ww, f'plume {key} R={len(radii)} seed {seed}')
+                if key == 'div_angle':
+                    rm = np.repeat(resolved, len(radii))
+                    same_pattern(gg[rm], ww[rm], f'plume {key} R={len(radii)} seed {seed}')
+                else:
+                    same_pattern(gg, ww, f'plume {key} R={len(radii)} seed {seed}')
                 if key == 'j_ion':
                     with np.errstate(all='ignore'):
-                        w3 = np.where(np.isfinite(ww), np.abs(ww), np.nan).reshape(args.n, 91, len(radii))
-                        peak = np.nan_to_num(np.nanmax(w3, axis=1))                                  # (n, R)
+                        w3 = np.where(np.isfinite(ww), np.abs(ww), 0.0).reshape(args.n, 91, len(radii))
+                        peak = np.max(w3, axis=1)                                  # (n, R)
                     fl = np.broadcast_to((flR + 1e-13 * peak)[:, None, :], (args.n, 91, len(radii))).reshape(-1)
                     fin = np.isfinite(ww) & np.isfinite(fl)
                     note(f'plume[R={len(radii)}].{key}', np.max(np.abs(gg[fin] - ww[fin]) / (np.abs(ww[fin]) + 1e10 * fl[fin] + 1e-300), initial=0.0))
