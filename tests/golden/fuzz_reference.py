@@ -98,5 +98,38 @@ def main():
     make_golden._save('plume_fuzz', **arrays, radii=np.array([1.0]))
 
 
+def fuzz_filter_outputs(cases: int = 300):
+    """drivers.filter_outputs (numpy and torch paths) against the reference's own `_filter_outputs` (gen_data.py:125-174,
+    pulled out of the script's AST as in make_golden.py) on random outputs with NaNs, heavy tails and zero-IQR fields."""
+    import ast
+    import torch
+    from hallthrusterpem_amd import drivers
+    src = (Path('/root/reference/scripts/gen_data.py')).read_text()
+    wanted = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name in ('_object_to_numeric', '_filter_outputs')]
+    ns = {'np': np, 'COORDS_STR_ID': '_coords'}
+    exec(compile(ast.Module(body=wanted, type_ignores=[]), 'gen_data.py[extract]', 'exec'), ns)
+    for seed in range(cases):
+        rng = np.random.default_rng(seed)
+        n = int(rng.integers(5, 400))
+        fo = {'a': rng.normal(0, 1, n), 'b': rng.standard_cauchy((n, int(rng.integers(1, 40)))), 'c': rng.normal(0, 1, (n, 3, 4)),
+              'a_coords': np.zeros((n, 3)), 'errors': np.zeros(n)}
+        for key in ('a', 'b', 'c'):
+            m = rng.random(fo[key].shape) < 0.02
+            fo[key][m] = np.nan if seed % 3 == 0 else fo[key][m] * 100
+        if seed % 5 == 0:
+            fo['b'][:] = 1.0
+        q = float(rng.choice([1.5, 3.0, 0.5]))
+        with np.errstate(all='ignore'):
+            rn, ro = ns['_filter_outputs'](dict(fo), iqr_factor=q)
+            gn, go = drivers.filter_outputs(dict(fo), iqr_factor=q)
+            tn, to = drivers.filter_outputs({key: torch.from_numpy(np.asarray(v)) for key, v in fo.items()}, iqr_factor=q)
+        assert set(rn) == set(gn) == set(tn) == {'a', 'b', 'c'}
+        for key in rn:
+            assert np.array_equal(rn[key], gn[key]) and np.array_equal(ro[key], go[key]), (seed, key)
+            assert np.array_equal(rn[key], tn[key].numpy()) and np.array_equal(ro[key], to[key].numpy()), (seed, key)
+    print(f'filter_outputs: {cases} random cases, NaN and outlier masks identical to the reference function (numpy and torch paths)')
+
+
 if __name__ == '__main__':
     main()
+    fuzz_filter_outputs()
