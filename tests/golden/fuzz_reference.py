@@ -130,6 +130,56 @@ def fuzz_filter_outputs(cases: int = 300):
     print(f'filter_outputs: {cases} random cases, NaN and outlier masks identical to the reference function (numpy and torch paths)')
 
 
+def fuzz_thruster_host(cases: int = 2000):
+    """The host-side thruster helpers against the reference's (thruster.py:93-181): `_default_model_fidelity` on random
+    fidelity tuples / configs / CFL numbers, `_convert_to_julia` / `_convert_to_pem` on random path maps -- results and
+    exception types identical."""
+    import copy
+    import warnings
+    import make_golden
+    from hallthrusterpem_amd.models import thruster as mine
+    _c, _p, ref, _k = make_golden._load_reference()
+    rng = np.random.default_rng(0)
+    for i in range(cases):
+        mf = () if i % 17 == 0 else (int(rng.integers(0, 5)), int(rng.integers(0, 4)))
+        cfg = {}
+        if i % 3:
+            cfg['config'] = {}
+        if i % 3 == 1:
+            cfg['config'].update({'domain': [0.0, float(rng.uniform(0.02, 0.2))], 'discharge_voltage': float(rng.uniform(100, 800)),
+                                  'cathode_coupling_voltage': float(rng.uniform(0, 60))})
+        if i % 5 == 0 and 'config' in cfg:
+            cfg['config']['propellant'] = str(rng.choice(['Xenon', 'Krypton', 'Argon']))
+        cfl = float(rng.uniform(0.05, 0.5))
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            assert ref._default_model_fidelity(mf, copy.deepcopy(cfg), cfl) == mine._default_model_fidelity(mf, copy.deepcopy(cfg), cfl), (mf, cfg)
+
+    def outcome(fn, *a):
+        try:
+            return fn(*a), None
+        except Exception as e:                                             # noqa: BLE001 -- the type is what is compared
+            return None, type(e).__name__
+
+    for i in range(cases):
+        keys = [f'k{j}' for j in range(int(rng.integers(1, 6)))]
+        p2j = {q: [str(rng.choice(['a', 'b', 'c', 'output', 'average', 'config', 'x'])) for _ in range(int(rng.integers(1, 4)))] for q in keys}
+        for q in keys:
+            if rng.random() < 0.3:
+                p2j[q][0] = 'output'
+        pem = {q: float(rng.normal()) for q in keys if rng.random() < 0.8}
+        if rng.random() < 0.2:
+            pem['unmapped'] = 1.0
+        ja, jb = {}, {}
+        _, ea = outcome(ref._convert_to_julia, copy.deepcopy(pem), ja, copy.deepcopy(p2j))
+        _, eb = outcome(mine._convert_to_julia, copy.deepcopy(pem), jb, copy.deepcopy(p2j))
+        assert ea == eb and (ea is not None or ja == jb), (pem, p2j, ea, eb)
+        if ea is None:
+            assert outcome(ref._convert_to_pem, copy.deepcopy(ja), copy.deepcopy(p2j)) == outcome(mine._convert_to_pem, copy.deepcopy(jb), copy.deepcopy(p2j))
+    print(f'thruster host helpers: {cases} + {cases} random cases identical to the reference functions')
+
+
 if __name__ == '__main__':
     main()
     fuzz_filter_outputs()
+    fuzz_thruster_host()
