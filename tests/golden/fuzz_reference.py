@@ -176,7 +176,39 @@ def fuzz_thruster_host(cases: int = 2000):
         assert ea == eb and (ea is not None or ja == jb), (pem, p2j, ea, eb)
         if ea is None:
             assert outcome(ref._convert_to_pem, copy.deepcopy(ja), copy.deepcopy(p2j)) == outcome(mine._convert_to_pem, copy.deepcopy(jb), copy.deepcopy(p2j))
-    print(f'thruster host helpers: {cases} + {cases} random cases identical to the reference functions')
+    # _format_hallthruster_jl_input (thruster.py:184-330) on random input subsets, anomalous-transport models, optional
+    # blocks and fidelities; the four random characters of the output file name are the only thing allowed to differ
+    import json
+    import re
+    assert ref.PEM_TO_JULIA == mine.PEM_TO_JULIA
+    in_keys = [q for q, v in ref.PEM_TO_JULIA.items() if v and v[0] != 'output']
+    norm = lambda o: re.sub(r'_[A-Z0-9]{4}\.json', '_XXXX.json', json.dumps(o, sort_keys=True, default=str))   # noqa: E731
+
+    def quiet(fn, *a, **kw):
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            return outcome(lambda: fn(*a, **kw))
+
+    for i in range(cases):
+        ti = {q: float(rng.uniform(0.001, 100)) for q in in_keys if rng.random() < 0.5}
+        typ = str(rng.choice(['TwoZoneBohm', 'GaussianBohm', 'NoAnom']))
+        cfg = {'anom_model': {'type': typ}}
+        if typ == 'TwoZoneBohm' and rng.random() < 0.7:
+            cfg['anom_model'].update({'c1': 0.00625, 'c2': 0.0625})
+        if typ == 'GaussianBohm' and rng.random() < 0.7:
+            cfg['anom_model'].update({'hall_min': 0.00625, 'hall_max': 0.0625})
+        if rng.random() < 0.5:
+            cfg['domain'] = [0, 0.08]
+        if rng.random() < 0.3:
+            cfg = None
+        kw = dict(thruster=None, config=cfg, simulation=None if rng.random() < 0.5 else {'dt': 1e-9, 'duration': 1e-3},
+                  postprocess=None if rng.random() < 0.5 else {'average_start_time': 5e-4},
+                  model_fidelity=None if rng.random() < 0.3 else (() if rng.random() < 0.2 else (int(rng.integers(0, 3)), int(rng.integers(0, 3)))),
+                  output_path=None if rng.random() < 0.5 else 'out.json')
+        a = quiet(ref._format_hallthruster_jl_input, copy.deepcopy(ti), ref.PEM_TO_JULIA, **copy.deepcopy(kw))
+        b = quiet(mine._format_hallthruster_jl_input, copy.deepcopy(ti), mine.PEM_TO_JULIA, **copy.deepcopy(kw))
+        assert norm(a) == norm(b), (ti, kw)
+    print(f'thruster host helpers: 3 x {cases} random cases identical to the reference functions')
 
 
 if __name__ == '__main__':
