@@ -858,6 +858,9 @@ __global__ __launch_bounds__(BLOCK) void plume_generic_kernel(PlumeIO io, const 
     const double thrust = have_T ? io.T[g] : 0.0;
 
     int invalid = (a1 <= 0.0) ? 1 : 0;
+    // `literal`: the Gaussians by direct exp() instead of the recurrence -- the sample is redone that way when pass 0
+    // finds a value below 1e-290 / non-positive or a non-finite amplitude (the deep tail, see exact_chunk above)
+    bool literal = false, uncertain = false;
     for (int pass = 0; pass < 2; ++pass) {  // pass 0: integrals + invalid flag; pass 1: profile stores
         for (int r = 0; r < R; ++r) {
             const double rad = radii[r];
@@ -865,12 +868,20 @@ __global__ __launch_bounds__(BLOCK) void plume_generic_kernel(PlumeIO io, const 
             const double j_cex = I_B0 * (1.0 - decay) / (2.0 * PEM_PI * (rad * rad));
             const double base = I_B0 * decay / (rad * rad);
             const double B1 = base * A1, B2 = base * A2;
+            if (!__builtin_isfinite(B1) || !__builtin_isfinite(B2)) uncertain = true;
             double e1 = (a1 == 0.0) ? __builtin_nan("") : 1.0, e2 = e1, r1 = r10, r2 = r20, den = 0.0, num = 0.0;
             for (int k = 0; k < NANG; ++k) {
+                if (literal) {
+                    const double alpha = k == NANG - 1 ? HALF_PI : (double)k * H;
+                    const double t1 = alpha / a1, t2 = alpha / a2;
+                    e1 = exp(-(t1 * t1));
+                    e2 = exp(-(t2 * t2));
+                }
                 const double f = B1 * e1 + B2 * e2;
                 const double ji = f + j_cex;
                 if (pass == 0) {
                     invalid |= (ji <= 0.0) ? 1 : 0;
+                    if (ji < 1e-290) uncertain = true;
                     den = fma(PEM_SIMPSON_CDEN[k], f, den);
                     num = fma(PEM_SIMPSON_CNUM[k], f, num);
                 } else {
@@ -887,6 +898,11 @@ __global__ __launch_bounds__(BLOCK) void plume_generic_kernel(PlumeIO io, const 
                 io.div[(size_t)g * R + r] = acos(cos_div);
                 if (have_T) io.Tc[(size_t)g * R + r] = thrust * cos_div;
             }
+        }
+        if (pass == 0 && uncertain && !literal) {   // redo pass 0 literally; pass 1 then stores the literal values
+            literal = true;
+            invalid = (a1 <= 0.0) ? 1 : 0;
+            pass = -1;
         }
     }
     if (io.invalid) io.invalid[g] = (uint8_t)invalid;
