@@ -84,6 +84,6 @@ def wild_plume_errors(inputs, got, want, torr2pa, radius=1.0):
               & ~(np.maximum(np.abs(a1), np.abs(a1 / x['c1'])) < 0.0044))
     gd, wd = np.asarray(got['div_angle']).reshape(-1), np.asarray(want['div_angle']).reshape(-1)
     gt, wt = np.asarray(got['T_c']).reshape(-1), np.asarray(want['T_c']).reshape(-1)
-    assert np.array_equal(np.isnan(gt), np.isnan(wt)), 'T_c NaN pattern differs'
+    assert np.array_equal(np.isnan(gt[ok]), np.isnan(wt[ok])), 'T_c NaN pattern differs'
     assert np.array_equal(np.isnan(gd[ok]), np.isnan(wd[ok])), 'div_angle NaN pattern differs'
     return {'j_ion': err_j, 'div_angle': div_err(gd[ok], wd[ok]), 'T_c': rel_err(gt[ok], wt[ok]), 'compared': int(ok.sum())}
