@@ -65,10 +65,32 @@ def wild(rng, n):
     return x
 
 
+def prior_campaign(batches, oc, constants, pem_v0_coupled, div_err, rel_err, n=1_250_000):
+    """Many shards of BASELINE configs[2] (1.25e6 samples from the PEM-v0 priors each), full and reduced mode against the
+    oracle at the plain 1e-10 tolerance: table boundaries, interval edges and rare corners of the prior box."""
+    from _inputs import coupled_inputs
+    worst = {}
+    for b in range(batches):
+        x = coupled_inputs(n, seed=5000 + b)
+        want = oc.coupled(x, constants.TORR_2_PA)
+        for name, got in (('full', pem_v0_coupled(x)), ('reduced', pem_v0_coupled(x, profile=False))):
+            assert np.array_equal(got['invalid'], want['invalid'])
+            for key in ('V_cc', 'I_B0', 'T', 'T_c', 'div_angle') + (('j_ion',) if name == 'full' else ()):
+                g, w = np.asarray(got[key]).reshape(-1), np.asarray(want[key]).reshape(-1)
+                e = div_err(g, w) if key == 'div_angle' else rel_err(g, w)
+                worst[f'{name}.{key}'] = max(worst.get(f'{name}.{key}', 0.0), e)
+    print(f'{batches} x {n} samples from the priors: worst relative errors vs the oracle')
+    for key, v in sorted(worst.items()):
+        print(f'  {key:20s} {v:.2e}')
+        assert v <= 1e-10, key
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--seeds', type=int, default=40)
     ap.add_argument('--n', type=int, default=20_000)
+    ap.add_argument('--priors', type=int, default=0, metavar='BATCHES',
+                    help='instead: BATCHES x 1.25e6 samples drawn from the PEM-v0 priors, full and reduced mode, strict 1e-10')
     args = ap.parse_args()
     import torch
     from conftest import div_err, rel_err
@@ -78,6 +100,8 @@ def main():
     from hallthrusterpem_amd.models import current_density, pem_v0_coupled
     oc.set_threads(16)
     worst = {}
+    if args.priors:
+        return prior_campaign(args.priors, oc, constants, pem_v0_coupled, div_err, rel_err)
     from hallthrusterpem_amd.compression import SVDCompression
     from hallthrusterpem_amd.likelihood import JionLikelihood
     frng = np.random.default_rng(7)
