@@ -50,3 +50,19 @@ def test_two_ranks_through_torch_distributed_run():
     assert line['n_gpus'] == 2 and line['config']['global_samples_per_step'] == 2 * 131072
     assert line['config']['gather'].startswith('qoi') and line['config']['value_without_gather'] >= line['value'] * 0.5
     assert line['cpu_baseline'] is None and line['config']['parallelism'] == 'sample-shard x2'
+
+
+def test_rccl_code_path_with_one_rank():
+    """PEM_BENCH_FORCE_DIST=1 takes the N > 1 branch (process group on the `nccl` = RCCL backend, overlapped
+    all_gather_into_tensor, barrier, max-over-ranks all_reduce) with a single rank -- the RCCL calls themselves, which two
+    ranks on one GPU cannot exercise."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PEM_BENCH_FORCE_DIST='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1',
+               LOCAL_RANK='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, str(ROOT / 'bench.py'), *SMALL, '--no-cpu-baseline'], capture_output=True, text=True,
+                         cwd=ROOT, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = _one_json_line(out.stdout)
+    assert line['n_gpus'] == 1 and line['config']['gather'].startswith('qoi') and line['config']['value_without_gather'] > 0
