@@ -181,9 +181,11 @@ class JionPosterior:
         return replay
 
 
-def capture_graph(body, device, warmup: int = 2):
+def capture_graph(body, device, warmup: int = 2, generator=None):
     """Run `body` (libpem_hip launches and torch ops on the current stream) `warmup` times on a side stream, then
-    record it once into a torch.cuda.CUDAGraph (a hipGraph).  Returns (graph, body's return value = static output)."""
+    record it once into a torch.cuda.CUDAGraph (a hipGraph).  A non-default torch `generator` that `body` draws from is
+    registered with the graph so that every replay advances its Philox offset.  Returns (graph, body's return value =
+    static output)."""
     import torch
     side = torch.cuda.Stream(device)
     side.wait_stream(torch.cuda.current_stream(device))
@@ -193,6 +195,8 @@ def capture_graph(body, device, warmup: int = 2):
     torch.cuda.current_stream(device).wait_stream(side)
     torch.cuda.synchronize(device)
     graph = torch.cuda.CUDAGraph()
+    if generator is not None:
+        graph.register_generator_state(generator)
     with torch.cuda.graph(graph):
         out = body()
     return graph, out
@@ -224,7 +228,7 @@ class Metropolis:
         if use_graph:           # the warm-up steps before the recording are undone: the chain starts at theta0
             theta_start, logp_start = self.theta.clone(), self.logp.clone()
             posterior.fresh = False
-            self._graph, _ = capture_graph_with_generator(self._step, dev, self.gen)
+            self._graph, _ = capture_graph(self._step, dev, generator=self.gen)
             posterior.fresh = fresh
             self.theta.copy_(theta_start)
             self.logp.copy_(logp_start)
@@ -259,21 +263,3 @@ class Metropolis:
     @property
     def acceptance(self):
         return self.accepted.double() / max(1, self.steps)
-
-
-def capture_graph_with_generator(body, device, gen, warmup: int = 2):
-    """`capture_graph` for a body that draws from a non-default torch generator: the generator is registered with the
-    graph so that every replay advances its Philox offset."""
-    import torch
-    side = torch.cuda.Stream(device)
-    side.wait_stream(torch.cuda.current_stream(device))
-    with torch.cuda.stream(side):
-        for _ in range(warmup):
-            body()
-    torch.cuda.current_stream(device).wait_stream(side)
-    torch.cuda.synchronize(device)
-    graph = torch.cuda.CUDAGraph()
-    graph.register_generator_state(gen)
-    with torch.cuda.graph(graph):
-        out = body()
-    return graph, out

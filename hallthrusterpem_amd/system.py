@@ -130,7 +130,6 @@ class PemV0System:
         distribution is (log-)uniform over its domain except custom NORMAL priors, which fall back to
         mean +- 3 sigma when not drawn from their pdf.  normalize: return the yml-normalised values.
         as_tensor: CUDA tensors (no host copy) instead of numpy arrays."""
-        import torch
         shape = (size,) if isinstance(size, (int, np.integer)) else tuple(size)
         n = int(np.prod(shape))
         cats = ({'operating', 'calibration', 'nuisance'} if use_pdf is True else set() if not use_pdf else set(use_pdf))
