@@ -908,6 +908,94 @@ __global__ __launch_bounds__(BLOCK) void plume_generic_kernel(PlumeIO io, const 
     if (io.invalid) io.invalid[g] = (uint8_t)invalid;
 }
 
+// ---------------------------------------------------------------------------------------------
+// sweep_radius arrays, 4 <= R <= RADII_MAX: one WAVE per sample.  For a sample the (91, R) block of j_ion is the outer
+// product  e1[k] B1[r] + e2[k] B2[r] + j_cex[r]  and is contiguous in memory: the wave computes the two Gaussians once
+// (91 direct exp() each -- literally the reference's expression, so its deep tail comes for free), the per-radius
+// amplitudes with lane = radius, and then streams the block with lane = linear index, 512 contiguous bytes per store.
+// The divergence integrals and plume.py:105's test run per radius lane over the staged Gaussians.  The lane-per-sample
+// kernel above writes the same block with a stride of 91 R doubles between lanes: 251 GB/s at R = 25 against
+// this kernel's several TB/s (tools/radii_probe.py).
+// ---------------------------------------------------------------------------------------------
+constexpr int RADII_MAX = 256;
+__global__ __launch_bounds__(BLOCK) void plume_radii_kernel(PlumeIO io, const double* __restrict__ radii, int R) {
+#pragma clang fp contract(off)
+    __shared__ double lds_all[BLOCK / WAVE][2 * 96 + 3 * RADII_MAX];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double* e1 = lds_all[wave];
+    double* e2 = e1 + 96;
+    double* B1 = e2 + 96;
+    double* B2 = B1 + RADII_MAX;
+    double* JC = B2 + RADII_MAX;
+    const long long nwaves = (long long)gridDim.x * (BLOCK / WAVE);
+    const bool have_T = io.T != nullptr;
+    const int step_r = WAVE % R, step_k = WAVE / R;
+    for (long long g = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (BLOCK / WAVE) + wave)); g < io.n; g += nwaves) {
+        // sample parameters: wave-uniform (every lane computes the same values)
+        const double P_B = io.P_b[g] * io.torr2pa;
+        const double c0 = io.c0[g], c1 = io.c1[g];
+        const double n_neutral = io.c4[g] * P_B + io.c5[g];
+        const double sigma = io.sigma[g], I_B0 = io.I_B0[g];
+        double a1 = io.c2[g] * P_B + io.c3[g];
+        if (a1 > HALF_PI) a1 = HALF_PI;
+        const double a2 = a1 / c1;
+        const double A1 = (1.0 - c0) / normaliser(a1, 1.0 / (a1 * a1), PEM_DPOLY);
+        const double A2 = c0 / normaliser(a2, 1.0 / (a2 * a2), PEM_DPOLY);
+        const double thrust = have_T ? io.T[g] : 0.0;
+        // the two Gaussians of plume.py:99-100 on the 91-point grid
+        for (int k = lane; k < NANG; k += WAVE) {
+            const double alpha = k == NANG - 1 ? HALF_PI : (double)k * GRID_H;
+            const double t1 = alpha / a1, t2 = alpha / a2;
+            e1[k] = exp(-(t1 * t1));
+            e2[k] = exp(-(t2 * t2));
+        }
+        wave_lds_sync();
+        // per radius (lane = radius): amplitudes, divergence integrals, plume.py:105
+        bool bad = a1 <= 0.0;
+        for (int r0 = 0; r0 < R; r0 += WAVE) {
+            const int r = r0 + lane;
+            if (r < R) {
+                const double rad = radii[r];
+                const double decay = exp(-rad * n_neutral * sigma);
+                const double j_cex = I_B0 * (1.0 - decay) / (2.0 * PEM_PI * (rad * rad));
+                const double base = I_B0 * decay / (rad * rad);
+                const double b1 = base * A1, b2 = base * A2;
+                double den = 0.0, num = 0.0;
+                for (int k = 0; k < NANG; ++k) {
+                    const double f = b1 * e1[k] + b2 * e2[k];
+                    if (f + j_cex <= 0.0) bad = true;
+                    den = __builtin_fma(PEM_SIMPSON_CDEN[k], f, den);
+                    num = __builtin_fma(PEM_SIMPSON_CNUM[k], f, num);
+                }
+                B1[r] = b1;
+                B2[r] = b2;
+                JC[r] = j_cex;
+                double cos_div = num / den;
+                if (cos_div == __builtin_inf()) cos_div = __builtin_nan("");
+                io.div[(size_t)g * R + r] = acos(cos_div);
+                if (have_T) io.Tc[(size_t)g * R + r] = thrust * cos_div;
+            }
+        }
+        const bool invalid = __ballot(bad) != 0;
+        wave_lds_sync();
+        // the (91, R) block, contiguous: lane = linear index k R + r
+        double* dst = io.j_ion + (size_t)g * NANG * R;
+        int k = lane / R, r = lane - k * R;
+        for (int idx = lane; idx < NANG * R; idx += WAVE) {
+            const double ji = (B1[r] * e1[k] + B2[r] * e2[k]) + JC[r];
+            __builtin_nontemporal_store(invalid ? 1e-20 : ji, dst + idx);
+            r += step_r;
+            k += step_k;
+            if (r >= R) {
+                r -= R;
+                ++k;
+            }
+        }
+        if (io.invalid && lane == 0) io.invalid[g] = (uint8_t)invalid;
+        wave_lds_sync();   // the staged rows are rewritten for the next sample
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void cathode_kernel(long long n, const double* __restrict__ P_b,
                                                         const double* __restrict__ V_a, const double* __restrict__ T_e,
                                                         const double* __restrict__ V_vac,
@@ -1317,8 +1405,16 @@ int pem_plume_f64_dev(size_t n, int n_radii, const double* radii, double torr2pa
     double* d_radii = nullptr;
     HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&d_radii), sizeof(double) * n_radii, st));
     HIP_TRY(hipMemcpyAsync(d_radii, radii, sizeof(double) * n_radii, hipMemcpyHostToDevice, st));
-    const size_t blocks = (n + BLOCK - 1) / BLOCK;
-    hipLaunchKernelGGL(plume_generic_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, st, io, d_radii, n_radii);
+    // wave per sample, coalesced (91, R) blocks: pays from about four radii on (per 1e5..1e6 samples, tools/radii_probe.py:
+    // R = 25: 7415 -> 683 us, R = 5: 2089 -> 1373 us, R = 2: 1191 -> 2904 us -- the per-sample 182 exp() need outputs to amortise)
+    if (n_radii >= 4 && n_radii <= RADII_MAX) {
+        size_t blocks = (n + BLOCK / WAVE - 1) / (BLOCK / WAVE);
+        if (blocks > 256 * 5) blocks = 256 * 5;   // persistent: 31 KB of LDS per workgroup, five per CU
+        hipLaunchKernelGGL(plume_radii_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, st, io, d_radii, n_radii);
+    } else {
+        const size_t blocks = (n + BLOCK - 1) / BLOCK;
+        hipLaunchKernelGGL(plume_generic_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, st, io, d_radii, n_radii);
+    }
     hipError_t le = hipGetLastError();
     HIP_TRY(hipFreeAsync(d_radii, st));
     HIP_TRY(le);

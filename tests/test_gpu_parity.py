@@ -459,3 +459,21 @@ def test_reduced_mode_table_and_loop_paths_agree_sample_by_sample(pem, oc):
     b2.run()
     torch.cuda.synchronize()
     assert np.array_equal(b2.qoi.cpu().numpy(), b.qoi.cpu().numpy()[:, perm], equal_nan=True)
+
+
+@pytest.mark.parametrize('R', [2, 3, 4, 64, 65, 70, 256, 257])
+def test_sweep_radius_counts_across_the_kernel_switches(pem, oc, R):
+    """sweep_radius arrays: lane-per-sample kernel below 4 and above 256 radii, wave-per-sample kernel in between (whose
+    radius loop runs in chunks of 64 lanes) -- every count at a switch against the oracle, invalid samples included."""
+    from hallthrusterpem_amd.models import current_density
+    n = 333
+    x = plume_inputs(n, seed=40 + R, priors=False)            # tests/test_plume.py ranges
+    x['c3'][:7], x['c2'][:7] = -0.1, 0.0                      # alpha1 <= 0: invalid samples
+    x['c0'][7:11] = 1.3                                       # negative beam amplitude: j_ion <= 0 somewhere
+    radii = np.linspace(0.4, 2.0, R)
+    out = current_density(x, sweep_radius=radii)
+    ref = oc.plume(*[x[k] for k in PLUME_KEYS], pem.constants.TORR_2_PA, T=x['T'], radii=radii)
+    assert out['j_ion'].shape == (n, 91, R) and out['div_angle'].shape == (n, R) and out['T_c'].shape == (n, R)
+    assert rel_err(out['j_ion'], ref['j_ion']) <= RTOL
+    assert div_err(out['div_angle'], ref['div_angle']) <= RTOL and rel_err(out['T_c'], ref['T_c']) <= RTOL
+    assert ref['invalid'].any() and np.array_equal(np.all(out['j_ion'].reshape(n, -1) == 1e-20, axis=1), ref['invalid'])

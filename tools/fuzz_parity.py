@@ -190,7 +190,7 @@ def main():
         # plume alone, several radii (generic kernel) and one radius (fast path)
         p = {k: x[k] for k in ('P_b', 'c0', 'c1', 'c2', 'c3', 'c4', 'c5', 'sigma_cex')}
         p['I_B0'], p['T'] = full['I_B0'], full['T']
-        for radii in ((1.0,), (0.5, 1.0, 2.5)):
+        for radii in ((1.0,), (0.5, 1.0, 2.5), (0.5, 0.8, 1.0, 1.7, 2.5)):   # fast path, lane-per-sample, wave-per-sample kernels
             with np.errstate(all='ignore'):
                 w = oc.plume(p['P_b'], p['c0'], p['c1'], p['c2'], p['c3'], p['c4'], p['c5'], p['sigma_cex'], p['I_B0'],
                              constants.TORR_2_PA, T=p['T'], radii=radii)
