@@ -912,8 +912,9 @@ __global__ __launch_bounds__(BLOCK) void plume_generic_kernel(PlumeIO io, const 
 // sweep_radius arrays, 4 <= R <= RADII_MAX: one WAVE per sample.  For a sample the (91, R) block of j_ion is the outer
 // product  e1[k] B1[r] + e2[k] B2[r] + j_cex[r]  and is contiguous in memory: the wave computes the two Gaussians once
 // (91 direct exp() each -- literally the reference's expression, so its deep tail comes for free), the per-radius
-// amplitudes with lane = radius, and then streams the block with lane = linear index, 512 contiguous bytes per store.
-// The divergence integrals and plume.py:105's test run per radius lane over the staged Gaussians.  The lane-per-sample
+// amplitudes with lane = radius, and then streams the block with lane = linear index, 512 contiguous bytes per store,
+// deciding plume.py:105 on the way.  The divergence integrals are linear in the amplitudes: four Simpson sums of the two
+// Gaussians per sample, combined per radius.  The lane-per-sample
 // kernel above writes the same block with a stride of 91 R doubles between lanes: 251 GB/s at R = 25 against
 // this kernel's several TB/s (tools/radii_probe.py).
 // ---------------------------------------------------------------------------------------------
@@ -942,16 +943,28 @@ __global__ __launch_bounds__(BLOCK) void plume_radii_kernel(PlumeIO io, const do
         const double A1 = (1.0 - c0) / normaliser(a1, 1.0 / (a1 * a1), PEM_DPOLY);
         const double A2 = c0 / normaliser(a2, 1.0 / (a2 * a2), PEM_DPOLY);
         const double thrust = have_T ? io.T[g] : 0.0;
-        // the two Gaussians of plume.py:99-100 on the 91-point grid
+        // the two Gaussians of plume.py:99-100 on the 91-point grid, and their four Simpson functionals: the sums of
+        // plume.py:117-123 are linear in the amplitudes, den[r] = B1[r] sum_k w_k e1[k] + B2[r] sum_k w_k e2[k]
+        double s1d = 0.0, s1n = 0.0, s2d = 0.0, s2n = 0.0;
         for (int k = lane; k < NANG; k += WAVE) {
             const double alpha = k == NANG - 1 ? HALF_PI : (double)k * GRID_H;
             const double t1 = alpha / a1, t2 = alpha / a2;
-            e1[k] = exp(-(t1 * t1));
-            e2[k] = exp(-(t2 * t2));
+            const double g1 = exp(-(t1 * t1)), g2 = exp(-(t2 * t2));
+            e1[k] = g1;
+            e2[k] = g2;
+            s1d = __builtin_fma(PEM_SIMPSON_CDEN[k], g1, s1d);
+            s1n = __builtin_fma(PEM_SIMPSON_CNUM[k], g1, s1n);
+            s2d = __builtin_fma(PEM_SIMPSON_CDEN[k], g2, s2d);
+            s2n = __builtin_fma(PEM_SIMPSON_CNUM[k], g2, s2n);
         }
-        wave_lds_sync();
-        // per radius (lane = radius): amplitudes, divergence integrals, plume.py:105
-        bool bad = a1 <= 0.0;
+#pragma unroll
+        for (int sh = 32; sh >= 1; sh >>= 1) {
+            s1d += __shfl_xor(s1d, sh);
+            s1n += __shfl_xor(s1n, sh);
+            s2d += __shfl_xor(s2d, sh);
+            s2n += __shfl_xor(s2n, sh);
+        }
+        // per radius (lane = radius): amplitudes and the divergence angle
         for (int r0 = 0; r0 < R; r0 += WAVE) {
             const int r = r0 + lane;
             if (r < R) {
@@ -960,37 +973,48 @@ __global__ __launch_bounds__(BLOCK) void plume_radii_kernel(PlumeIO io, const do
                 const double j_cex = I_B0 * (1.0 - decay) / (2.0 * PEM_PI * (rad * rad));
                 const double base = I_B0 * decay / (rad * rad);
                 const double b1 = base * A1, b2 = base * A2;
-                double den = 0.0, num = 0.0;
-                for (int k = 0; k < NANG; ++k) {
-                    const double f = b1 * e1[k] + b2 * e2[k];
-                    if (f + j_cex <= 0.0) bad = true;
-                    den = __builtin_fma(PEM_SIMPSON_CDEN[k], f, den);
-                    num = __builtin_fma(PEM_SIMPSON_CNUM[k], f, num);
-                }
                 B1[r] = b1;
                 B2[r] = b2;
                 JC[r] = j_cex;
+                double num = b1 * s1n + b2 * s2n, den = b1 * s1d + b2 * s2d;
+                if (!(fabs(b1) + fabs(b2) < 1e300)) {
+                    // amplitudes near the overflow threshold (exp(+x) of a negative density): the reference's
+                    // f_k = b1 e1[k] + b2 e2[k] overflows where the factored sums do not -- sum as it does (rare)
+                    num = 0.0;
+                    den = 0.0;
+                    for (int k = 0; k < NANG; ++k) {
+                        const double f = b1 * e1[k] + b2 * e2[k];
+                        den = __builtin_fma(PEM_SIMPSON_CDEN[k], f, den);
+                        num = __builtin_fma(PEM_SIMPSON_CNUM[k], f, num);
+                    }
+                }
                 double cos_div = num / den;
                 if (cos_div == __builtin_inf()) cos_div = __builtin_nan("");
                 io.div[(size_t)g * R + r] = acos(cos_div);
                 if (have_T) io.Tc[(size_t)g * R + r] = thrust * cos_div;
             }
         }
-        const bool invalid = __ballot(bad) != 0;
         wave_lds_sync();
-        // the (91, R) block, contiguous: lane = linear index k R + r
+        // the (91, R) block, contiguous: lane = linear index k R + r; plume.py:105 is decided on the way
         double* dst = io.j_ion + (size_t)g * NANG * R;
-        int k = lane / R, r = lane - k * R;
-        for (int idx = lane; idx < NANG * R; idx += WAVE) {
-            const double ji = (B1[r] * e1[k] + B2[r] * e2[k]) + JC[r];
-            __builtin_nontemporal_store(invalid ? 1e-20 : ji, dst + idx);
-            r += step_r;
-            k += step_k;
-            if (r >= R) {
-                r -= R;
-                ++k;
+        bool bad = a1 <= 0.0;
+        {
+            int k = lane / R, r = lane - k * R;
+            for (int idx = lane; idx < NANG * R; idx += WAVE) {
+                const double ji = (B1[r] * e1[k] + B2[r] * e2[k]) + JC[r];
+                bad |= ji <= 0.0;
+                __builtin_nontemporal_store(ji, dst + idx);
+                r += step_r;
+                k += step_k;
+                if (r >= R) {
+                    r -= R;
+                    ++k;
+                }
             }
         }
+        const bool invalid = __ballot(bad) != 0;
+        if (invalid)   // plume.py:106: the whole block becomes 1e-20 (rare: a second pass over it)
+            for (int idx = lane; idx < NANG * R; idx += WAVE) dst[idx] = 1e-20;
         if (io.invalid && lane == 0) io.invalid[g] = (uint8_t)invalid;
         wave_lds_sync();   // the staged rows are rewritten for the next sample
     }
