@@ -78,7 +78,9 @@ def main():
         with np.errstate(all='ignore'):
             a1 = np.minimum(x['c2'] * (x['P_b'] * k) + x['c3'], np.pi / 2)
             resolved = ~(np.maximum(np.abs(a1), np.abs(a1 / x['c1'])) < 0.0044)
-        assert np.array_equal(np.isnan(rd[resolved]), np.isnan(od[resolved])) and np.array_equal(np.isnan(rt), np.isnan(ot)), f'div/T_c NaN pattern (seed {seed})'
+        # (and a beam amplitude in the denormal range makes both Simpson sums a few denormal bits: 0/0 or noise on either side)
+        normal = ~((np.abs(base) < 1e-280) & (base != 0.0)) & resolved
+        assert np.array_equal(np.isnan(rd[normal]), np.isnan(od[normal])) and np.array_equal(np.isnan(rt[normal]), np.isnan(ot[normal])), f'div/T_c NaN pattern (seed {seed})'
         ok &= resolved
         worst['div_angle'] = max(worst['div_angle'], div_err(od[ok], rd[ok]))
         worst['T_c'] = max(worst['T_c'], rel_err(ot[ok], rt[ok]))
