@@ -909,7 +909,7 @@ __global__ __launch_bounds__(BLOCK) void plume_generic_kernel(PlumeIO io, const 
 }
 
 // ---------------------------------------------------------------------------------------------
-// sweep_radius arrays, 4 <= R <= RADII_MAX: one WAVE per sample.  For a sample the (91, R) block of j_ion is the outer
+// sweep_radius arrays, 2 <= R <= RADII_MAX: one WAVE per sample.  For a sample the (91, R) block of j_ion is the outer
 // product  e1[k] B1[r] + e2[k] B2[r] + j_cex[r]  and is contiguous in memory: the wave computes the two Gaussians once
 // (91 direct exp() each -- literally the reference's expression, so its deep tail comes for free), the per-radius
 // amplitudes with lane = radius, and then streams the block with lane = linear index, 512 contiguous bytes per store,
@@ -1429,9 +1429,10 @@ int pem_plume_f64_dev(size_t n, int n_radii, const double* radii, double torr2pa
     double* d_radii = nullptr;
     HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&d_radii), sizeof(double) * n_radii, st));
     HIP_TRY(hipMemcpyAsync(d_radii, radii, sizeof(double) * n_radii, hipMemcpyHostToDevice, st));
-    // wave per sample, coalesced (91, R) blocks: pays from about four radii on (per 1e5..1e6 samples, tools/radii_probe.py:
-    // R = 25: 7415 -> 683 us, R = 5: 2089 -> 1373 us, R = 2: 1191 -> 2904 us -- the per-sample 182 exp() need outputs to amortise)
-    if (n_radii >= 4 && n_radii <= RADII_MAX) {
+    // wave per sample, coalesced (91, R) blocks, literal Gaussians (per 1e5..1e6 samples, tools/radii_probe.py: R = 25:
+    // 7415 -> 660 us, R = 5: 2089 -> 920 us, R = 3: 1262 -> 1190 us; at R = 2 the per-sample 182 exp() cost more than the
+    // strided stores did, 1183 -> 1729 us, and buy the reference's exact deep-tail behaviour)
+    if (n_radii >= 2 && n_radii <= RADII_MAX) {
         size_t blocks = (n + BLOCK / WAVE - 1) / (BLOCK / WAVE);
         if (blocks > 256 * 5) blocks = 256 * 5;   // persistent: 31 KB of LDS per workgroup, five per CU
         hipLaunchKernelGGL(plume_radii_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, st, io, d_radii, n_radii);

@@ -74,7 +74,10 @@ def wild_plume_errors(inputs, got, want, torr2pa, radius=1.0):
     assert np.array_equal(np.all(gj == 1e-20, axis=1), np.all(wj == 1e-20, axis=1)), 'invalid rows differ'
     with np.errstate(all='ignore'):
         peak = np.nan_to_num(np.max(np.where(np.isfinite(wj), np.abs(wj), 0.0), axis=1, keepdims=True))
-        floor = 8 * np.finfo(float).eps * np.abs(x['I_B0'])[:, None] / (2 * np.pi * radius ** 2) + 1e-13 * peak
+        P_B0 = x['P_b'] * torr2pa
+        one_minus_decay = np.abs(1.0 - np.exp(-radius * (x['c4'] * P_B0 + x['c5']) * x['sigma_cex']))[:, None]
+        floor = (np.abs(x['I_B0'])[:, None] / (2 * np.pi * radius ** 2) * (8 * np.finfo(float).eps + 1e-13 * one_minus_decay)
+                 + 1e-13 * peak)
         fin = np.isfinite(wj) & np.isfinite(floor)
         err_j = float(np.max((np.abs(gj - wj) / (np.abs(wj) + 1e10 * floor + 1e-300))[fin], initial=0.0))
         P_B = x['P_b'] * torr2pa

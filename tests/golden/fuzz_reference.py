@@ -65,7 +65,8 @@ def main():
         n_nan += int(np.isnan(rj).any(axis=1).sum())
         with np.errstate(all='ignore'):
             peak = np.nan_to_num(np.max(np.where(np.isfinite(rj), np.abs(rj), 0.0), axis=1, keepdims=True))
-            floor = 8 * np.finfo(float).eps * np.abs(p['I_B0'])[:, None] / (2 * np.pi) + 1e-13 * peak
+            omd = np.abs(1.0 - np.exp(-(x['c4'] * (x['P_b'] * k) + x['c5']) * x['sigma_cex']))[:, None]
+            floor = np.abs(p['I_B0'])[:, None] / (2 * np.pi) * (8 * np.finfo(float).eps + 1e-13 * omd) + 1e-13 * peak
             fin = np.isfinite(rj) & np.isfinite(floor)
             worst['j_ion'] = max(worst['j_ion'], float(np.max((np.abs(oj - rj) / (np.abs(rj) + 1e10 * floor + 1e-300))[fin], initial=0.0)))
             base = p['I_B0'] * np.exp(-(x['c4'] * (x['P_b'] * k) + x['c5']) * x['sigma_cex'])

@@ -15,7 +15,8 @@ normal-range arithmetic:
   * V_cc = V_vac + T_e ln(1 + PB/PT) - T_e PB / (PT + P*) cancels for wild pressure ratios, j_cex carries the
     rounding of 1 - exp(-x), and with a negative amplitude or a negative j_cex (c0 outside [0, 1], negative density or
     cross-section) j_ion = j_beam + j_scat + j_cex cancels too: the tolerance is 1e-10 of the value plus 1e-13 of the
-    largest term (for j_ion: of the largest entry of that sample's profile), not 1e-10 of the cancelled result.
+    largest term (for j_ion: of the largest entry of that sample's profile and of |j_cex|), not 1e-10 of the cancelled
+    result.
 Prints the worst errors.
 
     python tools/fuzz_parity.py [--seeds 40] [--n 20000]
@@ -112,15 +113,21 @@ def main():
     comp = SVDCompression(norm='log10', rank=6)
     comp.basis = torch.from_numpy(np.ascontiguousarray(np.linalg.qr(frng.standard_normal((91, 6)))[0])).cuda()
 
+    where, current_seed = {}, [0]
+
     def note(key, val):
         assert val == val, f'{key}: the error metric itself is NaN'
-        worst[key] = max(worst.get(key, 0.0), float(val))
+        if float(val) > worst.get(key, 0.0):
+            worst[key], where[key] = float(val), current_seed[0]
 
     def same_pattern(a, b, what):
         assert np.array_equal(np.isnan(a), np.isnan(b)), f'NaN pattern differs: {what}'
         assert np.array_equal(np.isinf(a), np.isinf(b)) and np.array_equal(np.sign(a[np.isinf(a)]), np.sign(b[np.isinf(b)])), f'inf pattern differs: {what}'
 
     for seed in range(args.seeds):
+        current_seed[0] = seed
+        if seed % 25 == 0:
+            print(f'seed {seed} / {args.seeds}', flush=True)      # a long campaign must not look hung
         rng = np.random.default_rng(1000 + seed)
         x = wild(rng, args.n)
         with np.errstate(all='ignore'):
@@ -137,7 +144,9 @@ def main():
             beams_normal &= resolved
             lg = np.log(1.0 + x['P_b'] * k / (x['P_T'] * k))
             v_scale = np.abs(x['V_vac']) + np.abs(x['T_e'] * lg) + np.abs(x['T_e'] / ((x['P_T'] + x['Pstar']) * k) * (x['P_b'] * k))
-            j_floor = 8 * np.finfo(float).eps * np.abs(want['I_B0']) / (2 * np.pi)                   # rounding of 1 - decay
+            decay1 = np.exp(-(x['c4'] * (x['P_b'] * k) + x['c5']) * x['sigma_cex'])
+            # rounding of 1 - decay, and of the sum when a large negative j_cex (negative density) cancels the beams
+            j_floor = np.abs(want['I_B0']) / (2 * np.pi) * (8 * np.finfo(float).eps + 1e-13 * np.abs(1.0 - decay1))
         for name, got in (('full', full), ('reduced', red)):
             assert np.array_equal(got['invalid'], want['invalid']), f'invalid flags differ ({name}, seed {seed})'
             for key in ('V_cc', 'I_B0', 'T', 'T_c', 'div_angle') + (('j_ion',) if name == 'full' else ()):
@@ -200,7 +209,7 @@ def main():
                 nsig = (x['c4'] * (x['P_b'] * constants.TORR_2_PA) + x['c5']) * x['sigma_cex']
                 bR = p['I_B0'][:, None] * np.exp(-rr[None, :] * nsig[:, None]) / rr[None, :] ** 2
                 okR = ~((np.abs(bR) < 1e-280) & (bR != 0.0)) & resolved[:, None]                     # (n, R)
-                flR = 8 * np.finfo(float).eps * np.abs(p['I_B0'])[:, None] / (2 * np.pi * rr[None, :] ** 2)
+                flR = np.abs(p['I_B0'])[:, None] / (2 * np.pi * rr[None, :] ** 2) * (8 * np.finfo(float).eps + 1e-13 * np.abs(1.0 - np.exp(-rr[None, :] * nsig[:, None])))
             for key in ('j_ion', 'div_angle', 'T_c'):
                 gg, ww = np.asarray(g[key]).reshape(-1), np.asarray(w[key]).reshape(-1)
                 if key in ('div_angle', 'T_c'):
@@ -221,11 +230,10 @@ def main():
                         note(f'plume[R={len(radii)}].{key}{tag}', div_err(gg[m], ww[m]) if key == 'div_angle' else rel_err(gg[m], ww[m]))
     print(f'{args.seeds} seeds x {args.n} wild samples: NaN / inf / invalid patterns identical everywhere; worst errors:')
     for k, v in sorted(worst.items()):
-        print(f'  {k:28s} {v:.2e}')
-    # the multi-radius kernel (not a BASELINE configuration) runs one 91-step recurrence per beam instead of four chunks of
-    # 23: its Gaussians carry up to 91^2/2 ulp = 5e-13 relative, which arccos and the cancelling cases above amplify
+        print(f'  {k:28s} {v:.2e}   (seed {where[k]})')
+    # (the fused modes are compared with their two-launch pipelines, whose sums run in another order: 1e-9)
     for key, v in worst.items():
-        tol = 1e-6 if 'opposite sign' in key else (1e-9 if key.startswith(('plume[R=3]', 'fused.')) else 1e-10)
+        tol = 1e-6 if 'opposite sign' in key else (1e-9 if key.startswith('fused.') else 1e-10)
         assert v <= tol, f'tolerance exceeded: {key} {v:.2e}'
 
 
