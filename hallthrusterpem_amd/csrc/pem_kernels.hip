@@ -977,9 +977,11 @@ __global__ __launch_bounds__(BLOCK) void plume_radii_kernel(PlumeIO io, const do
                 B2[r] = b2;
                 JC[r] = j_cex;
                 double num = b1 * s1n + b2 * s2n, den = b1 * s1d + b2 * s2d;
-                if (!(fabs(b1) + fabs(b2) < 1e300)) {
-                    // amplitudes near the overflow threshold (exp(+x) of a negative density): the reference's
-                    // f_k = b1 e1[k] + b2 e2[k] overflows where the factored sums do not -- sum as it does (rare)
+                if (!(fabs(b1) + fabs(b2) < 1e300) || ((b1 < 0.0) != (b2 < 0.0) && b1 != 0.0 && b2 != 0.0)) {
+                    // Sum as the reference does (rare) when the amplitudes are near the overflow threshold (exp(+x) of a
+                    // negative density: its f_k = b1 e1[k] + b2 e2[k] overflows where the factored sums do not), or of
+                    // opposite sign (c0 outside [0, 1]): the reference cancels angle by angle, the factored form would
+                    // cancel two large sums at the end
                     num = 0.0;
                     den = 0.0;
                     for (int k = 0; k < NANG; ++k) {
