@@ -919,7 +919,7 @@ __global__ __launch_bounds__(BLOCK) void plume_generic_kernel(PlumeIO io, const 
 // this kernel's several TB/s (tools/radii_probe.py).
 // ---------------------------------------------------------------------------------------------
 constexpr int RADII_MAX = 256;
-__global__ __launch_bounds__(BLOCK) void plume_radii_kernel(PlumeIO io, const double* __restrict__ radii, int R) {
+__global__ __launch_bounds__(BLOCK) void plume_radii_kernel(PlumeIO io, const double* __restrict__ radii, int R, int ts) {
 #pragma clang fp contract(off)
     __shared__ double lds_all[BLOCK / WAVE][2 * 96 + 3 * RADII_MAX];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -931,18 +931,28 @@ __global__ __launch_bounds__(BLOCK) void plume_radii_kernel(PlumeIO io, const do
     const long long nwaves = (long long)gridDim.x * (BLOCK / WAVE);
     const bool have_T = io.T != nullptr;
     const int step_r = WAVE % R, step_k = WAVE / R;
-    for (long long g = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (BLOCK / WAVE) + wave)); g < io.n; g += nwaves) {
-        // sample parameters: wave-uniform (every lane computes the same values)
-        const double P_B = io.P_b[g] * io.torr2pa;
-        const double c0 = io.c0[g], c1 = io.c1[g];
-        const double n_neutral = io.c4[g] * P_B + io.c5[g];
-        const double sigma = io.sigma[g], I_B0 = io.I_B0[g];
-        double a1 = io.c2[g] * P_B + io.c3[g];
-        if (a1 > HALF_PI) a1 = HALF_PI;
-        const double a2 = a1 / c1;
-        const double A1 = (1.0 - c0) / normaliser(a1, 1.0 / (a1 * a1), PEM_DPOLY);
-        const double A2 = c0 / normaliser(a2, 1.0 / (a2 * a2), PEM_DPOLY);
-        const double thrust = have_T ? io.T[g] : 0.0;
+    // A wave takes `ts` (<= 64) consecutive samples at a time: their parameters are computed once, one lane per sample
+    // (coalesced input loads), and handed to the whole wave by shuffles as it walks through the blocks.  The host picks
+    // ts = 64 for large batches and smaller tiles when there would otherwise be too few of them to fill the chip.
+    const long long ntiles = (io.n + ts - 1) / ts;
+    for (long long t = blockIdx.x * (BLOCK / WAVE) + wave; t < ntiles; t += nwaves) {
+    const long long gl = (lane < ts && t * ts + lane < io.n) ? t * ts + lane : io.n - 1;    // idle lanes repeat the last sample
+    const double P_B_l = io.P_b[gl] * io.torr2pa;
+    const double c0_l = io.c0[gl], c1_l = io.c1[gl];
+    const double nn_l = io.c4[gl] * P_B_l + io.c5[gl], sigma_l = io.sigma[gl];
+    const double IB0_l = io.I_B0[gl];
+    double a1_l = io.c2[gl] * P_B_l + io.c3[gl];
+    if (a1_l > HALF_PI) a1_l = HALF_PI;
+    const double a2_l = a1_l / c1_l;
+    const double A1_l = (1.0 - c0_l) / normaliser(a1_l, 1.0 / (a1_l * a1_l), PEM_DPOLY);
+    const double A2_l = c0_l / normaliser(a2_l, 1.0 / (a2_l * a2_l), PEM_DPOLY);
+    const double thrust_l = have_T ? io.T[gl] : 0.0;
+    const int in_tile = (int)(io.n - t * ts < ts ? io.n - t * ts : ts);
+    for (int smp = 0; smp < in_tile; ++smp) {
+        const long long g = t * ts + smp;
+        const double a1 = __shfl(a1_l, smp), a2 = __shfl(a2_l, smp), A1 = __shfl(A1_l, smp), A2 = __shfl(A2_l, smp);
+        const double n_neutral = __shfl(nn_l, smp), sigma = __shfl(sigma_l, smp);
+        const double I_B0 = __shfl(IB0_l, smp), thrust = __shfl(thrust_l, smp);
         // the two Gaussians of plume.py:99-100 on the 91-point grid, and their four Simpson functionals: the sums of
         // plume.py:117-123 are linear in the amplitudes, den[r] = B1[r] sum_k w_k e1[k] + B2[r] sum_k w_k e2[k]
         double s1d = 0.0, s1n = 0.0, s2d = 0.0, s2n = 0.0;
@@ -1019,6 +1029,7 @@ __global__ __launch_bounds__(BLOCK) void plume_radii_kernel(PlumeIO io, const do
             for (int idx = lane; idx < NANG * R; idx += WAVE) dst[idx] = 1e-20;
         if (io.invalid && lane == 0) io.invalid[g] = (uint8_t)invalid;
         wave_lds_sync();   // the staged rows are rewritten for the next sample
+    }
     }
 }
 
@@ -1432,12 +1443,14 @@ int pem_plume_f64_dev(size_t n, int n_radii, const double* radii, double torr2pa
     HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&d_radii), sizeof(double) * n_radii, st));
     HIP_TRY(hipMemcpyAsync(d_radii, radii, sizeof(double) * n_radii, hipMemcpyHostToDevice, st));
     // wave per sample, coalesced (91, R) blocks, literal Gaussians (per 1e5..1e6 samples, tools/radii_probe.py: R = 25:
-    // 7415 -> 660 us, R = 5: 2089 -> 920 us, R = 3: 1262 -> 1190 us; at R = 2 the per-sample 182 exp() cost more than the
-    // strided stores did, 1183 -> 1729 us, and buy the reference's exact deep-tail behaviour)
+    // 7415 -> 614 us, R = 5: 2089 -> 795 us, R = 3: 1262 -> 940 us, R = 2: 1183 -> 1314 us)
     if (n_radii >= 2 && n_radii <= RADII_MAX) {
-        size_t blocks = (n + BLOCK / WAVE - 1) / (BLOCK / WAVE);
+        int ts = WAVE;                             // samples per wave tile: fewer when the batch is small
+        while (ts > 4 && (n + ts - 1) / ts < 256 * 20) ts >>= 1;
+        const size_t ntiles = (n + ts - 1) / ts;
+        size_t blocks = (ntiles + BLOCK / WAVE - 1) / (BLOCK / WAVE);
         if (blocks > 256 * 5) blocks = 256 * 5;   // persistent: 31 KB of LDS per workgroup, five per CU
-        hipLaunchKernelGGL(plume_radii_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, st, io, d_radii, n_radii);
+        hipLaunchKernelGGL(plume_radii_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, st, io, d_radii, n_radii, ts);
     } else {
         const size_t blocks = (n + BLOCK - 1) / BLOCK;
         hipLaunchKernelGGL(plume_generic_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, st, io, d_radii, n_radii);
