@@ -919,7 +919,10 @@ __global__ __launch_bounds__(BLOCK) void plume_generic_kernel(PlumeIO io, const 
 // this kernel's several TB/s (tools/radii_probe.py).
 // ---------------------------------------------------------------------------------------------
 constexpr int RADII_MAX = 256;
-__global__ __launch_bounds__(BLOCK) void plume_radii_kernel(PlumeIO io, const double* __restrict__ radii, int R, int ts) {
+struct RadiiArg {   // the sweep radii travel in the kernel arguments: no device allocation, no copy to wait for
+    double r[RADII_MAX];
+};
+__global__ __launch_bounds__(BLOCK) void plume_radii_kernel(PlumeIO io, RadiiArg radii_arg, int R, int ts) {
 #pragma clang fp contract(off)
     __shared__ double lds_all[BLOCK / WAVE][2 * 96 + 3 * RADII_MAX];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -978,7 +981,7 @@ __global__ __launch_bounds__(BLOCK) void plume_radii_kernel(PlumeIO io, const do
         for (int r0 = 0; r0 < R; r0 += WAVE) {
             const int r = r0 + lane;
             if (r < R) {
-                const double rad = radii[r];
+                const double rad = radii_arg.r[r];
                 const double decay = exp(-rad * n_neutral * sigma);
                 const double j_cex = I_B0 * (1.0 - decay) / (2.0 * PEM_PI * (rad * rad));
                 const double base = I_B0 * decay / (rad * rad);
@@ -1438,27 +1441,31 @@ int pem_plume_f64_dev(size_t n, int n_radii, const double* radii, double torr2pa
     PlumeIO io{(long long)n, torr2pa, radii[0], P_b, c0, c1, c2, c3, c4, c5, sigma_cex, I_B0, T, j_ion, div_angle, T_c, invalid};
     if (n_radii == 1 && aligned16(j_ion)) return dispatch_lanes<false, 1>(io, CoupledIO{}, st);
 
-    // general path: radii go to the device through a small stream-ordered allocation
-    double* d_radii = nullptr;
-    HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&d_radii), sizeof(double) * n_radii, st));
-    HIP_TRY(hipMemcpyAsync(d_radii, radii, sizeof(double) * n_radii, hipMemcpyHostToDevice, st));
-    // wave per sample, coalesced (91, R) blocks, literal Gaussians (per 1e5..1e6 samples, tools/radii_probe.py: R = 25:
-    // 7415 -> 614 us, R = 5: 2089 -> 795 us, R = 3: 1262 -> 940 us, R = 2: 1183 -> 1314 us)
     if (n_radii >= 2 && n_radii <= RADII_MAX) {
+        // wave per sample, coalesced (91, R) blocks, literal Gaussians (per 1e5..1e6 samples, tools/radii_probe.py: R = 25:
+        // 7415 -> 614 us, R = 5: 2089 -> 795 us, R = 3: 1262 -> 940 us, R = 2: 1183 -> 1314 us)
+        RadiiArg ra;
+        for (int r = 0; r < RADII_MAX; ++r) ra.r[r] = r < n_radii ? radii[r] : 1.0;
         int ts = WAVE;                             // samples per wave tile: fewer when the batch is small
         while (ts > 4 && (n + ts - 1) / ts < 256 * 20) ts >>= 1;
         const size_t ntiles = (n + ts - 1) / ts;
         size_t blocks = (ntiles + BLOCK / WAVE - 1) / (BLOCK / WAVE);
         if (blocks > 256 * 5) blocks = 256 * 5;   // persistent: 31 KB of LDS per workgroup, five per CU
-        hipLaunchKernelGGL(plume_radii_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, st, io, d_radii, n_radii, ts);
-    } else {
-        const size_t blocks = (n + BLOCK - 1) / BLOCK;
-        hipLaunchKernelGGL(plume_generic_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, st, io, d_radii, n_radii);
+        hipLaunchKernelGGL(plume_radii_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, st, io, ra, n_radii, ts);
+        HIP_TRY(hipGetLastError());
+        return PEM_OK;
     }
+    // lane-per-sample kernel (more than RADII_MAX radii; one radius with an unaligned j_ion): the radii go to the device
+    // through a small stream-ordered allocation, and -- `radii` being the caller's host memory -- this one path waits
+    // for the stream before it returns
+    double* d_radii = nullptr;
+    HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&d_radii), sizeof(double) * n_radii, st));
+    HIP_TRY(hipMemcpyAsync(d_radii, radii, sizeof(double) * n_radii, hipMemcpyHostToDevice, st));
+    const size_t blocks = (n + BLOCK - 1) / BLOCK;
+    hipLaunchKernelGGL(plume_generic_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, st, io, d_radii, n_radii);
     hipError_t le = hipGetLastError();
     HIP_TRY(hipFreeAsync(d_radii, st));
     HIP_TRY(le);
-    // `radii` is host memory owned by the caller: make sure the copy has left it before returning
     HIP_TRY(hipStreamSynchronize(st));
     return PEM_OK;
 }

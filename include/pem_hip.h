@@ -77,7 +77,9 @@ int pem_cathode_f64(size_t n, const double* P_b, const double* V_a, const double
 
 /* ---- current_density  (plume.py:21-159) ------------------------------------------------------
  * radii: HOST array of n_radii sweep radii in metres (the `sweep_radius` argument), also for the
- * _dev form.  T / T_c: optional thrust in, corrected thrust out (plume.py:136-140); pass NULL for
+ * _dev form (up to 256 radii travel in the kernel arguments; beyond that, and for one radius with a j_ion that is not
+ * 16-byte aligned, the _dev form copies them and waits for the stream before returning).  T / T_c: optional thrust
+ * in, corrected thrust out (plume.py:136-140); pass NULL for
  * both to skip.  j_ion: [n][91][n_radii]; div_angle, T_c: [n][n_radii]; invalid: [n] or NULL.   */
 int pem_plume_f64_dev(size_t n, int n_radii, const double* radii, double torr2pa, const double* P_b,
                       const double* c0, const double* c1, const double* c2, const double* c3,
