@@ -23,6 +23,14 @@
 //   * A round's S x 91 profile block is contiguous in j_ion (R = 1): it is staged in LDS in final order
 //     and leaves as 16-byte-per-lane, 1-KiB-per-instruction stores.
 //   * EPILOGUE, one lane per sample again: cos_div, arccos, T_c, coalesced 512-byte stores.
+//   * Without a profile (reduced-QoI mode) the rounds are skipped: the divergence integrals come from tabulated
+//     Simpson functionals of the beam width (simpson_functionals), per sample, wherever that is exact to rounding.
+//   * Where the reference's own exp() has left the normal range (deep tail of a narrow beam with j_cex = 0, infinite
+//     amplitudes) a chunk is re-evaluated literally (exact_chunk): "equal to the reference" beats "accurate" there.
+//   * The same tile loop carries the fused modes: Monte-Carlo inputs generated in the prelude (MC), the likelihood of
+//     measured current densities (JMODE 3) and the SVD compression (JMODE 4) consuming the profile on chip.
+//   Other kernels in this file: plume_radii_kernel / plume_generic_kernel (sweep_radius arrays), cathode, thruster,
+//   u_ion profile and the post-run filters.
 //
 // This file is written for gfx950 only: 64-wide waves, 160 KiB LDS, no portability layer.
 #include <hip/hip_runtime.h>
