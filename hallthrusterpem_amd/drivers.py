@@ -209,35 +209,41 @@ def sobol_indices(n_base: int, seed: int = 0, qois=QOI_NAMES, priors=None, fixed
     from . import _lib
     lib = _lib.load()
     NB = 1024                                                          # workgroups (= deterministic partial sums) per pass
-    partial = torch.empty((NB, nq, 2), dtype=torch.float64, device=dev)
     ptr = lambda x: C.c_void_p(x.data_ptr())                           # noqa: E731
+    all_rows = rows == [0, 1, 2]
+    # Per block one fused sample+evaluate launch and one partial-sum launch, nothing else: at 1e6-sample batches the
+    # GPU needs ~0.1 ms per block, and every extra torch op in this loop (copies, per-block reductions) costs the
+    # host about as much as a block costs the device.  The three Saltelli blocks of a step live in three batches, the
+    # kernels write their QoIs where the estimator reads them, and the partial sums of all blocks of a batch are reduced
+    # together.
+    batches, partial, mlast = None, None, -1
 
-    def block(batch, keep, first, swap):
-        batch.run_mc(design, first_index=first, swap_dim=swap)         # Saltelli block generated inside the kernel
-        keep.copy_(batch.qoi[rows])                                    # [nq][m]
+    def block(b, first, swap):
+        b.run_mc(design, first_index=first, swap_dim=swap)             # Saltelli block generated inside the kernel
+        return b.qoi if all_rows else b.qoi[rows].contiguous()         # [nq][m]
 
-    def sums(fA, fB, fAB, m):
+    def sums(slot, fA, fB, fAB, m):
         _lib.check(lib.pem_sobol_partial_f64_dev(m, nq, fA.stride(0), ptr(fA), ptr(fB), ptr(fAB) if fAB is not None else None,
-                                                 ptr(partial), NB, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
-        return partial.sum(dim=0)                                      # [nq][2]
+                                                 ptr(partial[slot]), NB, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
 
-    batch = fA = fB = fAB = None
     for off in range(lo, hi, bs):
         m = min(bs, hi - off)
-        if batch is None or batch.n != m:
-            batch = CoupledBatch(m, device=dev, profile=False, thruster_qoi=False)
-            fA, fB, fAB = (torch.empty((nq, m), dtype=torch.float64, device=dev) for _ in range(3))
-        block(batch, fA, off, -1)
-        block(batch, fB, off, -2)
-        s = sums(fA, fB, None, m)
-        acc[0] += s[:, 0]
-        acc[1] += s[:, 1]
-        acc[2] += 2 * m
+        if m != mlast:
+            batches = [CoupledBatch(m, device=dev, profile=False, thruster_qoi=False) for _ in range(3)]
+            partial = torch.empty((nd + 1, NB, nq, 2), dtype=torch.float64, device=dev)
+            mlast = m
+        fA = block(batches[0], off, -1)
+        fB = block(batches[1], off, -2)
+        sums(0, fA, fB, None, m)
         for j, d in enumerate(varied):
-            block(batch, fAB, off, d)
-            s = sums(fA, fB, fAB, m)
-            acc[3 + j] += s[:, 0]
-            acc[3 + nd + j] += s[:, 1]
+            fAB = block(batches[2], off, d)
+            sums(1 + j, fA, fB, fAB, m)
+        s = partial.sum(dim=1)                                         # [nd + 1][nq][2], one reduction per batch
+        acc[0] += s[0, :, 0]
+        acc[1] += s[0, :, 1]
+        acc[2] += 2 * m
+        acc[3:3 + nd] += s[1:, :, 0]
+        acc[3 + nd:] += s[1:, :, 1]
     if world > 1:
         dist.all_reduce(acc, group=group)
     cnt = acc[2]
