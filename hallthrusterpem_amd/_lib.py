@@ -88,7 +88,9 @@ def _share_torch_hip_runtime():
 
 
 def load():
-    """Load libpem_hip.so (building it with hipcc if the sources are newer) and bind every symbol."""
+    """Load libpem_hip.so and bind every symbol.  The in-tree library is rebuilt first when it is missing or older than
+    one of its sources (build.needs_build) and hipcc is available -- the .so is git-ignored, so a stale binary would
+    otherwise be tested silently after a source edit.  PEM_HIP_LIB names an experimental build and is loaded as is."""
     global _lib, _hip_runtime
     if _lib is not None:
         return _lib
@@ -96,9 +98,16 @@ def load():
         if _lib is not None:
             return _lib
         path = Path(os.environ.get('PEM_HIP_LIB', LIB_PATH))      # PEM_HIP_LIB: experimental builds (tools/build_variant.sh)
-        if not path.exists():
+        if 'PEM_HIP_LIB' not in os.environ:
             from . import build as _build
-            _build.build()
+            if _build.needs_build():
+                if _build.have_hipcc():
+                    _build.build()
+                elif not path.exists():
+                    raise RuntimeError('libpem_hip.so is missing and hipcc is not available to build it')
+                else:
+                    import warnings
+                    warnings.warn('libpem_hip.so is older than its sources and hipcc is not available: loading the stale library')
         _hip_runtime = _share_torch_hip_runtime()
         lib = C.CDLL(str(path))
         for name, (res, args) in SIGNATURES.items():

@@ -8,7 +8,7 @@ PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
 SRCS = [PKG / 'csrc' / 'pem_kernels.hip', PKG / 'csrc' / 'pem_sampler.hip', PKG / 'csrc' / 'pem_svd.hip', PKG / 'csrc' / 'pem_likelihood.hip', PKG / 'csrc' / 'pem_surrogate.hip']
 LIB = PKG / 'libpem_hip.so'
-DEPS = SRCS + [PKG / 'csrc' / 'pem_tables.h', PKG / 'csrc' / 'pem_common.h', PKG / 'csrc' / 'pem_philox.h', ROOT / 'include' / 'pem_hip.h']
+DEPS = SRCS + sorted((PKG / 'csrc').glob('*.h')) + [ROOT / 'include' / 'pem_hip.h']
 
 
 def hipcc() -> str:
@@ -18,11 +18,28 @@ def hipcc() -> str:
     return exe
 
 
+def have_hipcc() -> bool:
+    return Path(shutil.which('hipcc') or '/opt/rocm/bin/hipcc').exists()
+
+
+STAMP = PKG / 'libpem_hip.so.srchash'
+
+
+def source_hash() -> str:
+    """Digest of every file the library is compiled from (content, not mtime: a snapshot copy may not keep times)."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in DEPS:
+        h.update(d.name.encode())
+        h.update(d.read_bytes() if d.exists() else b'<missing>')
+    return h.hexdigest()
+
+
 def needs_build() -> bool:
-    if not LIB.exists():
+    """True when the library is missing or was built from other sources than the ones in the tree."""
+    if not LIB.exists() or not STAMP.exists():
         return True
-    t = LIB.stat().st_mtime
-    return any(d.exists() and d.stat().st_mtime > t for d in DEPS)
+    return STAMP.read_text().strip() != source_hash()
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
@@ -35,6 +52,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         print(' '.join(cmd))
     env = dict(os.environ)
     subprocess.run(cmd, check=True, env=env)
+    STAMP.write_text(source_hash() + '\n')
     return LIB
 
 

@@ -151,6 +151,26 @@ __device__ __forceinline__ double normaliser(double a, double u, const double* p
     return D;
 }
 
+
+// plume.py:40, 56-61: the pressure in Pa, the neutral density and the two beam widths.  numpy rounds c4*P_B and c2*P_B
+// before adding c5 / c3; a contracted fma() would not, and when c2*P_B cancels c3 the reference's alpha1 is exactly 0
+// (invalid sample, NaN normaliser) where the fma leaves a tiny number of either sign.  Shared by every plume kernel so
+// that one sample gets one answer whatever path evaluates it.
+struct PlumeSetup {
+    double n_neutral, a1, a2;
+};
+__device__ __forceinline__ PlumeSetup plume_setup(double P_b, double c1, double c2, double c3, double c4, double c5, double k) {
+#pragma clang fp contract(off)
+    PlumeSetup o;
+    const double P_B = P_b * k;
+    o.n_neutral = c4 * P_B + c5;
+    double a1 = c2 * P_B + c3;
+    if (a1 > HALF_PI) a1 = HALF_PI;   // upper clip only (plume.py:60); NaN stays NaN
+    o.a1 = a1;
+    o.a2 = a1 / c1;
+    return o;
+}
+
 // ---------------------------------------------------------------------------------------------
 // kernel arguments
 // ---------------------------------------------------------------------------------------------
@@ -324,6 +344,15 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 #ifndef PEM_NT_STORES
 #define PEM_NT_STORES 1
 #endif
+// tuning knobs of the fused modes (file scope: a #define inside a function body does not survive -save-temps)
+#ifndef PEM_LATENT_UNROLL
+#define PEM_LATENT_UNROLL 4   // angle-loop unroll of the fused compression mode
+#endif
+#ifndef PEM_LOGLIK_MU
+#define PEM_LOGLIK_MU 2       // measurement records in flight per lane in the fused likelihood mode
+#endif
+// (#pragma unroll takes a constant expression; a macro there is not expanded in preprocessed output)
+constexpr int LATENT_UNROLL = PEM_LATENT_UNROLL;
 __device__ __forceinline__ void stream_store(f64x2 v, f64x2* dst) {
 #if PEM_NT_STORES
     __builtin_nontemporal_store(v, dst);
@@ -456,11 +485,8 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
         have_T = io.T != nullptr;
     }
     // plume.py:40-61
-    const double P_B = in.P_b * io.torr2pa;
-    const double n_neutral = in.c4 * P_B + in.c5;
-    double a1 = in.c2 * P_B + in.c3;
-    if (a1 > HALF_PI) a1 = HALF_PI;
-    const double a2 = a1 / in.c1;
+    const PlumeSetup ps = plume_setup(in.P_b, in.c1, in.c2, in.c3, in.c4, in.c5, io.torr2pa);
+    const double n_neutral = ps.n_neutral, a1 = ps.a1, a2 = ps.a2;
     const double u1 = 1.0 / (a1 * a1), u2 = 1.0 / (a2 * a2);
     const double A1 = (1.0 - in.c0) / normaliser(a1, u1, m.poly);  // plume.py:64-73
     const double A2 = in.c0 / normaliser(a2, u2, m.poly);          // plume.py:75-85
@@ -539,10 +565,7 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
             double2 wq[CH];
             if constexpr (LATENT) {
                 // a rolled loop: 23 inlined log10 evaluations in one basic block cost 512 registers and scratch
-#ifndef PEM_LATENT_UNROLL
-#define PEM_LATENT_UNROLL 4
-#endif
-#pragma unroll PEM_LATENT_UNROLL
+#pragma unroll LATENT_UNROLL
                 for (int j = 0; j < CH; ++j) {
                     const double2 w = my_w[j];
                     const double f = X1 + X2;
@@ -653,9 +676,6 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
                     const double4* mt = reinterpret_cast<const double4*>(m.meas) + cond * (io.n_ang | 1);   // {weight, y, 1/std, k}
                     const JT* row = tile + s * NANG;
                     double acc = 0.0;
-#ifndef PEM_LOGLIK_MU
-#define PEM_LOGLIK_MU 2
-#endif
                     constexpr int MU = PEM_LOGLIK_MU;   // records in flight per lane: the k -> row[k] chain is two LDS latencies deep
                     for (int a0 = c; a0 < io.n_ang; a0 += MU * L) {
                         double4 e[MU];
@@ -748,9 +768,14 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
 template <int JMODE, bool MC>
 constexpr int min_waves_per_simd() { return (MC && JMODE == 0) ? 3 : 1; }
 
+// Only the fused Monte-Carlo instantiations carry the ~340-byte design in their kernel arguments.
+struct NoDesign {};
+template <bool MC>
+using DesignArg = typename std::conditional<MC, McDesign, NoDesign>::type;
+
 template <int L, bool COUPLED, int JMODE, bool MC = false>
 __global__ __launch_bounds__(WAVE * WPB) __attribute__((amdgpu_waves_per_eu(min_waves_per_simd<JMODE, MC>())))
-void plume_r1_kernel(PlumeIO io, CoupledIO cio, long long ntiles, McDesign mc) {
+void plume_r1_kernel(PlumeIO io, CoupledIO cio, long long ntiles, DesignArg<MC> mc) {
     static_assert(!MC || COUPLED, "the fused Monte-Carlo mode generates the coupled inputs");
     static_assert(L == 2 || L == 4 || L == 8, "lanes per sample");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -849,13 +874,10 @@ void plume_r1_kernel(PlumeIO io, CoupledIO cio, long long ntiles, McDesign mc) {
 __global__ __launch_bounds__(BLOCK) void plume_generic_kernel(PlumeIO io, const double* __restrict__ radii, int R) {
     const long long g = (long long)blockIdx.x * BLOCK + threadIdx.x;
     if (g >= io.n) return;
-    const double P_B = io.P_b[g] * io.torr2pa;
     const double c0 = io.c0[g], c1 = io.c1[g];
-    const double n_neutral = io.c4[g] * P_B + io.c5[g];
+    const PlumeSetup ps = plume_setup(io.P_b[g], c1, io.c2[g], io.c3[g], io.c4[g], io.c5[g], io.torr2pa);
+    const double n_neutral = ps.n_neutral, a1 = ps.a1, a2 = ps.a2;
     const double sigma = io.sigma[g], I_B0 = io.I_B0[g];
-    double a1 = io.c2[g] * P_B + io.c3[g];
-    if (a1 > HALF_PI) a1 = HALF_PI;
-    const double a2 = a1 / c1;
     const double u1 = 1.0 / (a1 * a1), u2 = 1.0 / (a2 * a2);
     const double A1 = (1.0 - c0) / normaliser(a1, u1, PEM_DPOLY);
     const double A2 = c0 / normaliser(a2, u2, PEM_DPOLY);
@@ -948,13 +970,11 @@ __global__ __launch_bounds__(BLOCK) void plume_radii_kernel(PlumeIO io, RadiiArg
     const long long ntiles = (io.n + ts - 1) / ts;
     for (long long t = blockIdx.x * (BLOCK / WAVE) + wave; t < ntiles; t += nwaves) {
     const long long gl = (lane < ts && t * ts + lane < io.n) ? t * ts + lane : io.n - 1;    // idle lanes repeat the last sample
-    const double P_B_l = io.P_b[gl] * io.torr2pa;
     const double c0_l = io.c0[gl], c1_l = io.c1[gl];
-    const double nn_l = io.c4[gl] * P_B_l + io.c5[gl], sigma_l = io.sigma[gl];
+    const PlumeSetup ps_l = plume_setup(io.P_b[gl], c1_l, io.c2[gl], io.c3[gl], io.c4[gl], io.c5[gl], io.torr2pa);
+    const double nn_l = ps_l.n_neutral, sigma_l = io.sigma[gl];
     const double IB0_l = io.I_B0[gl];
-    double a1_l = io.c2[gl] * P_B_l + io.c3[gl];
-    if (a1_l > HALF_PI) a1_l = HALF_PI;
-    const double a2_l = a1_l / c1_l;
+    const double a1_l = ps_l.a1, a2_l = ps_l.a2;
     const double A1_l = (1.0 - c0_l) / normaliser(a1_l, 1.0 / (a1_l * a1_l), PEM_DPOLY);
     const double A2_l = c0_l / normaliser(a2_l, 1.0 / (a2_l * a2_l), PEM_DPOLY);
     const double thrust_l = have_T ? io.T[gl] : 0.0;
@@ -1221,7 +1241,8 @@ int launch_r1(const PlumeIO& io, const CoupledIO& cio, hipStream_t st, const McD
     if (cached_per_cu > by_regs) cached_per_cu = by_regs;
     if (cached_per_cu > cap) cached_per_cu = cap;
     if (int rc = fast_grid(cached_per_cu, ntiles, &grid)) return rc;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * WPB), lds, st, io, cio, ntiles, mc);
+    if constexpr (MC) hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * WPB), lds, st, io, cio, ntiles, mc);
+    else hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * WPB), lds, st, io, cio, ntiles, NoDesign{});
     HIP_TRY(hipGetLastError());
     return PEM_OK;
 }

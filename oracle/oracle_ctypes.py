@@ -87,6 +87,23 @@ def plume(P_b, c0, c1, c2, c3, c4, c5, sigma_cex, I_B0, torr2pa, T=None, radii=(
     return {'j_ion': j, 'div_angle': div, 'T_c': tc, 'invalid': inv.astype(bool)}
 
 
+def plume_terms(P_b, c0, c1, c2, c3, c4, c5, sigma_cex, I_B0, torr2pa, radii=(1.0,)):
+    """Sizes of the terms behind each plume result (oracle_plume_terms_f64): what tests/parity_rules.py turns into
+    per-entry tolerances.  Returns arrays of shape (n, R) -- X1, X2, j_cex, decay, den, num, den_abs, num_abs -- and the
+    beam widths a1, a2 of shape (n,)."""
+    ins = (P_b, c0, c1, c2, c3, c4, c5, sigma_cex, I_B0)
+    n = np.broadcast(*ins).size
+    arrs = [_f64(x, n) for x in ins]
+    rad = _f64(np.atleast_1d(radii))
+    t = np.empty((n, rad.size, 8))
+    al = np.empty((n, 2))
+    rc = lib().oracle_plume_terms_f64(C.c_long(n), C.c_int(rad.size), _p(rad), C.c_double(torr2pa), *[_p(a) for a in arrs], _p(t), _p(al))
+    assert rc == 0
+    out = {k: t[:, :, i] for i, k in enumerate(('X1', 'X2', 'j_cex', 'decay', 'den', 'num', 'den_abs', 'num_abs'))}
+    out['a1'], out['a2'], out['radii'] = al[:, 0], al[:, 1], rad
+    return out
+
+
 def thruster(V_a, V_cc, mdot_a, a_1):
     n = np.broadcast(V_a, V_cc, mdot_a, a_1).size
     arrs = [_f64(x, n) for x in (V_a, V_cc, mdot_a, a_1)]

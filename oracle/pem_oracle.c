@@ -236,6 +236,51 @@ int oracle_plume_f64(long n, int R, const double* radii, double torr2pa, const d
     return 0;
 }
 
+/* The term decomposition behind one plume result, for the conditioning-aware tolerances of the parity tests
+ * (tests/parity_rules.py): j_ion[m] = X1 g1[m] + X2 g2[m] + j_cex and cos_div = num / den are sums that cancel for
+ * inputs outside the priors (negative amplitudes or densities); a bound on the error of such a sum needs the size of
+ * its terms, not of its result.  terms: [n][R][8] = {X1, X2, j_cex, decay, den, num, den_abs, num_abs} with
+ * X1 = base*A1, X2 = base*A2 and den_abs / num_abs the same Simpson sums over |w_m| (|jb| + |js|) ...; alpha: [n][2]. */
+int oracle_plume_terms_f64(long n, int R, const double* radii, double torr2pa, const double* P_b, const double* c0,
+                           const double* c1, const double* c2, const double* c3, const double* c4, const double* c5,
+                           const double* sigma_cex, const double* I_B0, double* terms, double* alpha) {
+    if (n < 0 || R < 1) return 1;
+    init_tables();
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < n; ++i) {
+        double P_B = P_b[i] * torr2pa;
+        double nn = c4[i] * P_B + c5[i];
+        double a1 = c2[i] * P_B + c3[i];
+        if (a1 > ORACLE_PI / 2) a1 = ORACLE_PI / 2;
+        double a2 = a1 / c1[i];
+        double A1 = (1.0 - c0[i]) / oracle_normaliser(a1), A2 = c0[i] / oracle_normaliser(a2);
+        alpha[2 * i] = a1;
+        alpha[2 * i + 1] = a2;
+        for (int r = 0; r < R; ++r) {
+            double rad = radii[r];
+            double decay = exp(-rad * nn * sigma_cex[i]);
+            double base = I_B0[i] * decay / (rad * rad);
+            double X1 = base * A1, X2 = base * A2;
+            double den = 0, num = 0, dabs = 0, nabs = 0;
+            for (int m = 0; m < PEM_NANGLE; ++m) {
+                double u1 = g_alpha[m] / a1, u2 = g_alpha[m] / a2;
+                double jb = X1 * exp(-(u1 * u1)), js = X2 * exp(-(u2 * u2));
+                int mm = PEM_NANGLE - 1 - m;
+                double d = (jb + js) * g_cos[mm], da = (fabs(jb) + fabs(js)) * fabs(g_cos[mm]);
+                den += g_w[mm] * d;
+                num += g_w[mm] * (d * g_sin[mm]);
+                dabs += fabs(g_w[mm]) * da;
+                nabs += fabs(g_w[mm]) * (da * fabs(g_sin[mm]));
+            }
+            double* t = terms + ((size_t)i * R + r) * 8;
+            t[0] = X1; t[1] = X2;
+            t[2] = I_B0[i] * (1.0 - decay) / (2.0 * ORACLE_PI * (rad * rad));
+            t[3] = decay; t[4] = den; t[5] = num; t[6] = dabs; t[7] = nabs;
+        }
+    }
+    return 0;
+}
+
 /* ----------------------------------------------------------------------------------------------
  * tests/sim_hallthruster.jl:35-48 -- the reference's analytic stand-in for HallThruster.jl.
  * q and m_ion are the script's own literals (1.6e-19, 2.18e-25), not CODATA values.

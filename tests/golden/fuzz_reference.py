@@ -28,17 +28,22 @@ sys.path.insert(0, str(ROOT / 'tests'))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--seeds', type=int, default=60)
+    ap.add_argument('--seed-list', type=int, nargs='*', default=[], help='further seeds; with --no-fixture a quick look at given seeds')
     ap.add_argument('--n', type=int, default=20_000)
+    ap.add_argument('--no-fixture', action='store_true', help='do not rewrite tests/golden/plume_fuzz.npz')
     args = ap.parse_args()
     import make_golden
+    import parity_rules as pr
     from fuzz_parity import wild
     from oracle import oracle_ctypes as oc
     cathode, plume, _thruster, _const = make_golden._load_reference()
     k = make_golden.TORR_2_PA
     keep_in, keep_out = [], []
     worst = {'V_cc': 0.0, 'j_ion': 0.0, 'div_angle': 0.0, 'T_c': 0.0}
+    seen = {'j_ion': {'cond': 0.0, 'tau_seen': 0.0, 'n_cancelling': 0}, 'div_angle': {'cond': 0.0, 'tau_seen': 0.0, 'n_cancelling': 0}}
     n_invalid = n_nan = 0
-    for seed in range(args.seeds):
+    seeds = list(range(args.seeds)) + [s_ for s_ in args.seed_list if s_ >= args.seeds]
+    for seed in seeds:
         x = wild(np.random.default_rng(1000 + seed), args.n)
         with np.errstate(all='ignore'):
             v_ref = np.asarray(cathode.cathode_coupling({q: x[q] for q in ('P_b', 'V_a', 'T_e', 'V_vac', 'Pstar', 'P_T')})['V_cc'])
@@ -48,54 +53,45 @@ def main():
             p['I_B0'], p['T'] = th['I_B0'], th['T']
             ref = plume.current_density(dict(p), sweep_radius=1.0)
             orc = oc.plume(p['P_b'], p['c0'], p['c1'], p['c2'], p['c3'], p['c4'], p['c5'], p['sigma_cex'], p['I_B0'], k, T=p['T'])
+            terms = oc.plume_terms(p['P_b'], p['c0'], p['c1'], p['c2'], p['c3'], p['c4'], p['c5'], p['sigma_cex'], p['I_B0'], k)
+            bounds = pr.plume_bounds(terms, p['I_B0'])
         assert np.array_equal(np.isnan(v_ref), np.isnan(v_or)), f'V_cc NaN pattern (seed {seed})'
         with np.errstate(all='ignore'):          # same operations in the same order; numpy's log and libm's differ by an ulp
             lg = np.log(1.0 + x['P_b'] * k / (x['P_T'] * k))
             v_scale = np.abs(x['V_vac']) + np.abs(x['T_e'] * lg) + np.abs(x['T_e'] / ((x['P_T'] + x['Pstar']) * k) * (x['P_b'] * k))
         fin = np.isfinite(v_ref) & np.isfinite(v_scale)
         assert np.array_equal(np.isinf(v_ref), np.isinf(v_or))
-        worst['V_cc'] = max(worst['V_cc'], float(np.max(np.abs(v_ref[fin] - v_or[fin]) / np.maximum(np.maximum(np.abs(v_ref[fin]), v_scale[fin]), 1e-300), initial=0.0)))
+        worst['V_cc'] = max(worst['V_cc'], float(np.max(np.abs(v_ref[fin] - v_or[fin]) / (np.abs(v_ref[fin]) + (pr.TAU / pr.TOL) * v_scale[fin] + 1e-300), initial=0.0)))
         assert worst['V_cc'] == worst['V_cc']
         rj, oj = np.asarray(ref['j_ion'], dtype=np.float64), orc['j_ion'].reshape(args.n, 91)
-        assert np.array_equal(np.isnan(rj), np.isnan(oj)), f'j_ion NaN pattern (seed {seed})'
-        assert np.array_equal(np.isinf(rj), np.isinf(oj)), f'j_ion inf pattern (seed {seed})'
         inv_ref = np.all(rj == 1e-20, axis=1)
         assert np.array_equal(inv_ref, orc['invalid']), f'invalid samples differ (seed {seed})'
         n_invalid += int(inv_ref.sum())
         n_nan += int(np.isnan(rj).any(axis=1).sum())
-        with np.errstate(all='ignore'):
-            peak = np.nan_to_num(np.max(np.where(np.isfinite(rj), np.abs(rj), 0.0), axis=1, keepdims=True))
-            omd = np.abs(1.0 - np.exp(-(x['c4'] * (x['P_b'] * k) + x['c5']) * x['sigma_cex']))[:, None]
-            floor = np.abs(p['I_B0'])[:, None] / (2 * np.pi) * (8 * np.finfo(float).eps + 1e-13 * omd) + 1e-13 * peak
-            fin = np.isfinite(rj) & np.isfinite(floor)
-            worst['j_ion'] = max(worst['j_ion'], float(np.max((np.abs(oj - rj) / (np.abs(rj) + 1e10 * floor + 1e-300))[fin], initial=0.0)))
-            base = p['I_B0'] * np.exp(-(x['c4'] * (x['P_b'] * k) + x['c5']) * x['sigma_cex'])
-            ok = ~((np.abs(base) < 1e-280) & (base != 0.0)) & (x['c0'] >= 0) & (x['c0'] <= 1)
-        from conftest import div_err, rel_err
-        rd, od = np.asarray(ref['div_angle'], dtype=np.float64), orc['div_angle'].reshape(-1)
-        rt, ot = np.asarray(ref['T_c'], dtype=np.float64), orc['T_c'].reshape(-1)
-        # both beams narrower than a quarter of the 1-degree grid: only the centreline point contributes, cos_div = 1 to the
-        # last bit, and arccos gives 0 or NaN depending on that bit (scipy's Simpson and a sequential sum round differently)
-        with np.errstate(all='ignore'):
-            a1 = np.minimum(x['c2'] * (x['P_b'] * k) + x['c3'], np.pi / 2)
-            resolved = ~(np.maximum(np.abs(a1), np.abs(a1 / x['c1'])) < 0.0044)
-        # (and a beam amplitude in the denormal range makes both Simpson sums a few denormal bits: 0/0 or noise on either side)
-        normal = ~((np.abs(base) < 1e-280) & (base != 0.0)) & resolved
-        assert np.array_equal(np.isnan(rd[normal]), np.isnan(od[normal])) and np.array_equal(np.isnan(rt[normal]), np.isnan(ot[normal])), f'div/T_c NaN pattern (seed {seed})'
-        ok &= resolved
-        worst['div_angle'] = max(worst['div_angle'], div_err(od[ok], rd[ok]))
-        worst['T_c'] = max(worst['T_c'], rel_err(ot[ok], rt[ok]))
+        # the oracle against the reference under the very rules the device path is held to against the oracle
+        r = pr.j_ion_error(oj, rj, bounds, f'j_ion seed {seed}')
+        d = pr.divergence_error(orc['div_angle'], ref['div_angle'], orc['T_c'], ref['T_c'], bounds, f'seed {seed}')
+        worst['j_ion'] = max(worst['j_ion'], r['err'])
+        worst['div_angle'] = max(worst['div_angle'], d['err_div'])
+        worst['T_c'] = max(worst['T_c'], d['err_tc'])
+        for key, rec in (('j_ion', r), ('div_angle', d)):
+            seen[key]['cond'] = max(seen[key]['cond'], rec['cond'])
+            seen[key]['tau_seen'] = max(seen[key]['tau_seen'], rec['tau_seen'])
+            seen[key]['n_cancelling'] += rec['n_cancelling']
         # fixture: a slice of every seed plus every sample that sits in one of the special regimes
         with np.errstate(all='ignore'):
+            base = p['I_B0'] * np.exp(-(x['c4'] * (x['P_b'] * k) + x['c5']) * x['sigma_cex'])
             special = inv_ref | np.isnan(rj).any(axis=1) | np.isinf(rj).any(axis=1) | ((np.abs(base) < 1e-280) & (base != 0))
         pick = np.zeros(args.n, dtype=bool)
         pick[:12] = True
         pick[np.flatnonzero(special)[:14]] = True
         keep_in.append({q: v[pick] for q, v in p.items()})
-        keep_out.append({'j_ion': rj[pick], 'div_angle': rd[pick], 'T_c': rt[pick]})
-    print(f'{args.seeds} seeds x {args.n} wild samples, oracle vs reference: {n_invalid} invalid and {n_nan} NaN '
-          f'samples, patterns identical; worst errors {worst}')
-    assert worst['j_ion'] <= 1e-10 and worst['div_angle'] <= 1e-10 and worst['T_c'] <= 1e-10 and worst['V_cc'] <= 1e-13
+        keep_out.append({'j_ion': rj[pick], 'div_angle': np.asarray(ref['div_angle'], dtype=np.float64)[pick], 'T_c': np.asarray(ref['T_c'], dtype=np.float64)[pick]})
+    print(f'{len(seeds)} seeds x {args.n} wild samples, oracle vs reference: {n_invalid} invalid and {n_nan} NaN '
+          f'samples, patterns identical; worst errors (1e-10 = at the bound of tests/parity_rules.py) {worst}; cancellation met: {seen}')
+    assert worst['j_ion'] <= 1e-10 and worst['div_angle'] <= 1e-10 and worst['T_c'] <= 1e-10 and worst['V_cc'] <= 1e-10
+    if args.no_fixture or args.seed_list:
+        return
     arrays = {f'in_{q}': np.concatenate([d[q] for d in keep_in]) for q in keep_in[0]}
     arrays.update({f'out_{q}': np.concatenate([d[q] for d in keep_out]) for q in keep_out[0]})
     make_golden._save('plume_fuzz', **arrays, radii=np.array([1.0]))

@@ -173,6 +173,31 @@ def main():
     rr = np.array([0.5, 1.0, 2.5])
     _save('plume_edges_r3', **{f'in_{k}': v for k, v in pin.items()}, radii=rr, **_plume_out(plume, pin, rr))
 
+    # exact cancellation in the two affine set-up expressions (plume.py:56,59): c3 = -fl(c2 P_B) makes alpha1 exactly 0 in
+    # the reference (invalid sample, NaN normaliser) where a fused multiply-add would leave the rounding error of the
+    # product, of either sign; its two neighbours in c3 give alpha1 = +-1 ulp(c3).  Likewise c5 = -fl(c4 P_B): n = 0,
+    # exp(0) = 1, j_cex = 0 exactly.
+    rng = np.random.default_rng(20260211)
+    N = 96
+    Pb = 10 ** rng.uniform(-7, -4, N)
+    c2 = rng.uniform(-15, 15, N)
+    c2[c2 == 0] = 1.0
+    prod = c2 * (Pb * TORR_2_PA)
+    c3 = -prod
+    c3[1::3] = np.nextafter(c3[1::3], np.inf)
+    c3[2::3] = np.nextafter(c3[2::3], -np.inf)
+    c4 = 10 ** rng.uniform(18, 22, N)
+    c5 = 10 ** rng.uniform(14, 18, N)
+    half = np.arange(N) >= N // 2                 # second half: the density cancels instead, alpha1 stays ordinary
+    c3[half] = rng.uniform(0.2, 1.5, half.sum())
+    c5[half] = -(c4[half] * (Pb[half] * TORR_2_PA))
+    nudge = np.flatnonzero(half)[1::3]
+    c5[nudge] = np.nextafter(c5[nudge], np.inf)
+    pin = {'P_b': Pb, 'c0': rng.uniform(0, 1, N), 'c1': rng.uniform(0.1, 0.9, N), 'c2': c2, 'c3': c3, 'c4': c4, 'c5': c5,
+           'sigma_cex': rng.uniform(51e-20, 58e-20, N), 'I_B0': rng.uniform(2, 8, N), 'T': rng.uniform(0.02, 0.2, N)}
+    _save('plume_cancel', **{f'in_{k}': v for k, v in pin.items()}, radii=np.array([1.0]), **_plume_out(plume, pin, 1.0))
+    _save('plume_cancel_r3', **{f'in_{k}': v for k, v in pin.items()}, radii=rr, **_plume_out(plume, pin, rr))
+
     # wild inputs far outside the priors (signs, zeros, huge/tiny magnitudes): NaN / inf / invalid patterns must agree
     rng = np.random.default_rng(20260107)
     N = 600

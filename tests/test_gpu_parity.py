@@ -66,7 +66,7 @@ def test_cathode_golden(pem):
 
 
 @pytest.mark.parametrize('name', ['plume_random_r1', 'plume_priors_r1', 'plume_alpha_sweep', 'plume_random_r5',
-                                  'plume_edges', 'plume_edges_r3', 'plume_wild', 'plume_pressure_sweep'])
+                                  'plume_edges', 'plume_edges_r3', 'plume_cancel', 'plume_cancel_r3', 'plume_wild', 'plume_pressure_sweep'])
 def test_plume_golden(pem, name):
     from hallthrusterpem_amd.models import current_density
     g = load_golden(name)

@@ -53,7 +53,7 @@ def test_cathode_edges_scalar_sweep():
 
 
 @pytest.mark.parametrize('name', ['plume_random_r1', 'plume_priors_r1', 'plume_alpha_sweep', 'plume_random_r5',
-                                  'plume_edges', 'plume_edges_r3', 'plume_wild'])
+                                  'plume_edges', 'plume_edges_r3', 'plume_cancel', 'plume_cancel_r3', 'plume_wild'])
 def test_plume_against_reference(name):
     g = load_golden(name)
     T = g.get('in_T')
