@@ -7,6 +7,7 @@ An amisc YAML can point at them unchanged apart from the package name, e.g.
 from .cathode import cathode_coupling
 from .coupled import pem_v0_coupled
 from .plume import current_density
-from .thruster import PEM_TO_JULIA, thruster_analytic
+from .thruster import PEM_TO_JULIA, hallthruster_jl, thruster_analytic
 
-__all__ = ['cathode_coupling', 'current_density', 'thruster_analytic', 'pem_v0_coupled', 'PEM_TO_JULIA']
+# the reference's three (src/hallmd/models/__init__.py:15-19) first, then what this package adds
+__all__ = ['cathode_coupling', 'hallthruster_jl', 'current_density', 'thruster_analytic', 'pem_v0_coupled', 'PEM_TO_JULIA']

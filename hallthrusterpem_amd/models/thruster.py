@@ -11,12 +11,18 @@ In scope:
     solver, evaluated batched on the GPU.  It is a TEST DOUBLE: it lets V_cc -> (I_B0, T) -> plume be
     coupled without the external 1-D fluid solver, and says nothing about real thruster physics.
 
-Out of scope: launching HallThruster.jl (a third-party Julia program run as a subprocess,
-thruster.py:281-375) and reading device files from disk (hallmd.utils.load_thruster).
+  * `hallthruster_jl`: the model callable itself (thruster.py:378-512), same signature and return keys; the run between
+    "format the inputs" and "convert the outputs" goes through a pluggable `run_simulation(json_input, ...)` whose
+    default, `run_analytic_double`, evaluates what tests/sim_hallthruster.jl computes -- on the GPU, batched.
+
+Out of scope: launching HallThruster.jl (a third-party Julia program run as a subprocess, thruster.py:281-375); a
+caller who has it passes `run_simulation=hallmd.models.thruster.run_hallthruster_jl`.
 """
 import copy
+import json
 import random
 import string
+import time
 import warnings
 from pathlib import Path
 
@@ -24,7 +30,10 @@ import numpy as np
 
 from .. import _lib, _marshal as m, constants
 
-__all__ = ['PEM_TO_JULIA', 'thruster_analytic', 'check_thruster_outputs']
+__all__ = ['PEM_TO_JULIA', 'HALLTHRUSTER_VERSION_DEFAULT', 'hallthruster_jl', 'run_analytic_double', 'thruster_analytic',
+           'check_thruster_outputs']
+
+HALLTHRUSTER_VERSION_DEFAULT = '0.18.7'      # thruster.py:38; only names the Julia environment handed to a custom backend
 
 # PEM variable name -> path into the HallThruster.jl input/output structure.  These are interface
 # names shared with the solver's JSON schema (the reference keeps them in models/pem_to_julia.json).
@@ -104,20 +113,23 @@ def _default_model_fidelity(model_fidelity: tuple, json_config: dict, cfl: float
         gas = 'Xenon'
     ion_mass = constants.MOLECULAR_WEIGHTS[gas] / constants.AVOGADRO_CONSTANT / 1000      # kg
     cell = float(domain[1]) / (num_cells + 1)
-    speed = np.sqrt(2 * ncharge * constants.FUNDAMENTAL_CHARGE * (v_anode - v_cathode) / ion_mass)
-    return {'num_cells': num_cells, 'ncharge': ncharge, 'dt': float(cfl * cell / speed)}
+    energy = 2 * ncharge * constants.FUNDAMENTAL_CHARGE * (v_anode - v_cathode) / ion_mass
+    if m.is_torch(energy):                                  # a batch of runs whose voltages live on the GPU
+        return {'num_cells': num_cells, 'ncharge': ncharge, 'dt': cfl * cell / energy.sqrt()}
+    dt = cfl * cell / np.sqrt(energy)
+    return {'num_cells': num_cells, 'ncharge': ncharge, 'dt': float(dt) if np.ndim(dt) == 0 else dt}
 
 
 def _format_hallthruster_jl_input(thruster_inputs: dict, pem_to_julia: dict, thruster=None, config=None,
                                   simulation=None, postprocess=None, model_fidelity=(2, 2), output_path=None,
                                   fidelity_function=None) -> dict:
     """Build the `{'config', 'simulation', 'postprocess'}` dict HallThruster.run_simulation expects
-    (thruster.py:184-278).  `thruster` must be a dict (or None): reading a device directory from disk
-    belongs to hallmd.utils.load_thruster, which is out of scope here."""
+    (thruster.py:184-278).  A `thruster` given as a str / Path is a device directory read with utils.load_thruster."""
     doc = {key: copy.deepcopy(val) if val is not None else {}
            for key, val in (('config', config), ('simulation', simulation), ('postprocess', postprocess))}
     if isinstance(thruster, (str, Path)):
-        raise NotImplementedError('pass the thruster as a dict (hallmd.utils.load_thruster reads device files)')
+        from ..utils import load_thruster
+        thruster = load_thruster(thruster)
     if thruster is not None:
         doc['config']['thruster'] = thruster
     duration = doc['simulation'].get('duration', 1e-3)
@@ -130,9 +142,11 @@ def _format_hallthruster_jl_input(thruster_inputs: dict, pem_to_julia: dict, thr
         stem = 'hallthruster_jl'
         if name := doc['config'].get('thruster', {}).get('name'):
             stem += f'_{name}'
-        if volts := doc['config'].get('discharge_voltage'):
+        # (a batch of runs shares one file: voltage and flow rate go into the name only when they are single numbers)
+        volts, flow = doc['config'].get('discharge_voltage'), doc['config'].get('anode_mass_flow_rate')
+        if np.ndim(volts) == 0 and not m.is_torch(volts) and volts:
             stem += f'_{round(volts)}V'
-        if flow := doc['config'].get('anode_mass_flow_rate'):
+        if np.ndim(flow) == 0 and not m.is_torch(flow) and flow:
             stem += f'_{flow:.1e}kg_s'
         stem += '_' + ''.join(random.choices(string.ascii_uppercase + string.digits, k=4)) + '.json'
         doc['postprocess']['output_file'] = str((Path(output_path) / stem).resolve())
@@ -241,3 +255,144 @@ def thruster_analytic(inputs: dict, num_cells: int | None = None, domain=(0.0, 0
         ret['u_ion'] = u if on_device else u.cpu().numpy()
         ret['u_ion_coords'] = z if on_device else z.cpu().numpy()
     return ret
+
+
+def run_analytic_double(json_input: dict | str | Path, jl_env=None, jl_script=None, **kwargs) -> dict:
+    """Default `run_simulation` backend of `hallthruster_jl`: the reference's analytic stand-in for
+    `HallThruster.run_simulation` (tests/sim_hallthruster.jl), evaluated on the GPU through `pem_thruster_f64[_dev]` and
+    `pem_thruster_uion_f64_dev`.  Call signature of `run_hallthruster_jl` (thruster.py:281-375); `jl_env`, `jl_script`
+    and the subprocess keyword arguments have nothing to act on and are ignored.
+
+    Reads what the script reads (sim_hallthruster.jl:26-33): config.discharge_voltage, config.cathode_coupling_voltage,
+    config.anode_mass_flow_rate, config.anom_model.model.c1, simulation.grid.num_cells, config.domain -- scalars for
+    one run, arrays (numpy or CUDA tensors) of one loop shape for a batch of runs.  Returns the structure the script
+    writes (sim_hallthruster.jl:50-66): `{'output': {'average': {...}}, 'config', 'simulation', 'postprocess'}`, with
+    plain floats / lists for a single run (what json.load of the script's file gives) and arrays for a batch, and
+    writes it to postprocess.output_file when that is set.  A TEST DOUBLE: no thruster physics."""
+    if isinstance(json_input, dict):
+        doc = json_input
+    else:
+        with open(json_input, 'r') as fp:
+            doc = json.load(fp)
+    if 'input' in doc and 'config' not in doc:        # an output file fed back in (thruster.py:309-310)
+        doc = doc['input']
+    try:
+        cfg = doc['config']
+        ins = {'V_a': cfg['discharge_voltage'], 'V_cc': cfg['cathode_coupling_voltage'], 'mdot_a': cfg['anode_mass_flow_rate'],
+               'a_1': cfg['anom_model']['model']['c1']}
+        ncells = int(doc['simulation']['grid']['num_cells'])
+        domain = cfg['domain']
+    except KeyError as e:
+        raise KeyError(f'run_analytic_double: the input has no {e.args[0]!r} (sim_hallthruster.jl:26-31 reads '
+                       f'config.discharge_voltage, .cathode_coupling_voltage, .anode_mass_flow_rate, .anom_model.model.c1, '
+                       f'.domain and simulation.grid.num_cells)') from e
+    single = all(np.ndim(v) == 0 for v in ins.values() if not m.is_torch(v)) and not any(m.is_torch(v) and v.dim() > 0 for v in ins.values())
+    q = thruster_analytic(ins, num_cells=ncells, domain=(float(domain[0]), float(domain[1])))
+    names = {'thrust': 'T', 'ion_current': 'I_B0', 'current_eff': 'eta_c', 'discharge_current': 'I_d', 'v_exh': 'v_exh',
+             'mass_eff': 'eta_m', 'voltage_eff': 'eta_v', 'anode_eff': 'eta_a'}
+    if single:
+        host = {k: (v.cpu().numpy() if m.is_torch(v) else np.asarray(v)) for k, v in q.items()}
+        avg = {jl: float(host[pem].reshape(-1)[0]) for jl, pem in names.items()}
+        avg['ui'] = [host['u_ion'].reshape(-1, ncells)[0].tolist()]
+        avg['z'] = host['u_ion_coords'].tolist()
+    else:
+        avg = {jl: q[pem] for jl, pem in names.items()}
+        avg['ui'] = [q['u_ion']]
+        avg['z'] = q['u_ion_coords']
+    out = {'output': {'average': avg}, 'config': doc['config'], 'simulation': doc['simulation'], 'postprocess': doc.get('postprocess', {})}
+    if target := doc.get('postprocess', {}).get('output_file'):
+        def plain(o):
+            if m.is_torch(o):
+                o = o.detach().cpu().numpy()
+            if isinstance(o, np.ndarray):
+                return o.tolist()
+            if isinstance(o, (np.floating, np.integer)):
+                return o.item()
+            if isinstance(o, Path):
+                return str(o)
+            raise TypeError(f'{type(o).__name__} is not JSON serialisable')
+        Path(target).parent.mkdir(parents=True, exist_ok=True)
+        with open(target, 'w', encoding='utf-8') as fp:
+            json.dump(out, fp, ensure_ascii=False, indent=4, default=plain)
+    return out
+
+
+def hallthruster_jl(thruster_inputs: dict | None = None, thruster: Path | str | dict = 'SPT-100', config: dict | None = None,
+                    simulation: dict | None = None, postprocess: dict | None = None, model_fidelity: tuple = (2, 2),
+                    output_path: str | Path | None = None, version: str = HALLTHRUSTER_VERSION_DEFAULT,
+                    pem_to_julia: dict | None = None, fidelity_function=None, julia_script: str | Path | None = None,
+                    run_kwargs: dict | None = None, shock_threshold: float | None = None, run_simulation=None) -> dict:
+    """The thruster component of the PEM (`hallmd.models.thruster.hallthruster_jl`, thruster.py:378-512;
+    pem_v0_SPT-100.yml:63): the reference's signature, argument meaning, return keys and error behaviour.
+
+    format the PEM inputs (`_format_hallthruster_jl_input`) -> `run_simulation(json_data, jl_env=, jl_script=,
+    **run_kwargs)` -> `_convert_to_pem` -> ValueError for a non-physical run (thrust or beam current < 0) or, with
+    `shock_threshold`, for an ion velocity that peaks before that axial position -> `model_cost` (s), `output_path`
+    (relative to `output_path`, when one was given) and the raw `thruster_output`.
+
+    `run_simulation` is the one addition to the reference's signature.  The reference always launches HallThruster.jl
+    (`run_hallthruster_jl`, a Julia subprocess: out of scope here); the default here is `run_analytic_double`, the
+    reference's own analytic stand-in for that run (tests/sim_hallthruster.jl, what tests/test_thruster.py:70-114 runs
+    through `julia_script`), evaluated on the GPU.  Pass `hallmd.models.thruster.run_hallthruster_jl` to run the real
+    solver.  `version` / `julia_script` / `run_kwargs` are handed to the backend as in the reference.
+
+    Batches: the reference runs one simulation per call.  Here `thruster_inputs` may also hold arrays (numpy or CUDA
+    tensors) of one loop shape; the QoIs then come back as arrays of that shape, `model_cost` is the wall time per
+    sample, and the two filters, instead of raising, return the samples the reference would have raised for as NaN
+    (all QoIs of that sample) with their messages in `errors` {flat index: message}."""
+    mapping = copy.deepcopy(PEM_TO_JULIA)
+    if pem_to_julia is not None:
+        mapping.update(pem_to_julia)
+    thruster_inputs = {} if thruster_inputs is None else thruster_inputs
+    json_data = _format_hallthruster_jl_input(thruster_inputs, thruster=thruster, config=config, simulation=simulation,
+                                              postprocess=postprocess, model_fidelity=model_fidelity, output_path=output_path,
+                                              pem_to_julia=mapping, fidelity_function=fidelity_function)
+    jl_env = None
+    if version is not None:
+        jl_env = Path('~/.julia/environments/').expanduser() / f'hallthruster_{version}'      # thruster.py:83-90
+    backend = run_analytic_double if run_simulation is None else run_simulation
+    kwargs = {'check': True} if run_kwargs is None else run_kwargs
+    t1 = time.time()
+    sim_results = backend(json_data, jl_env=jl_env, jl_script=julia_script, **kwargs)
+    if any(m.is_torch(v) and v.is_cuda for v in sim_results.get('output', {}).get('average', {}).values()):
+        import torch
+        torch.cuda.synchronize()
+    t2 = time.time()
+    out = _convert_to_pem(sim_results, mapping)
+
+    thrust, beam = out.get('T', 0), out.get('I_B0', 0)
+    batch = np.ndim(thrust) > 0 or np.ndim(beam) > 0 or (m.is_torch(thrust) and thrust.dim() > 0)
+    if not batch:
+        if thrust < 0 or beam < 0:
+            raise ValueError(f'Exception due to non-physical case: thrust={thrust} N, beam current={beam} A')
+        if shock_threshold is not None:
+            z, u = out.get('u_ion_coords'), out.get('u_ion')
+            if z is not None and u is not None:
+                if (z_max := z[int(np.argmax(u))]) < shock_threshold:
+                    raise ValueError(f'Exception due to shock-like behavior: max ion velocity occurs at z={z_max:.3f} m')
+        out['model_cost'] = t2 - t1
+    else:
+        bad = check_thruster_outputs(out, shock_threshold)
+        bad_h = bad.cpu().numpy() if m.is_torch(bad) else np.asarray(bad)
+        n = int(bad_h.size)
+        if bad_h.any():
+            nonphys = ((_to_host(thrust) < 0) | (_to_host(beam) < 0)).reshape(-1)
+            out['errors'] = {int(i): ('Exception due to non-physical case' if nonphys[i] else 'Exception due to shock-like behavior')
+                             for i in np.flatnonzero(bad_h.reshape(-1))}
+            for key, val in out.items():
+                if key in ('u_ion_coords', 'errors'):
+                    continue
+                if m.is_torch(val):
+                    val[bad if val.dim() == bad.dim() else bad.unsqueeze(-1).expand_as(val)] = float('nan')
+                elif isinstance(val, np.ndarray):
+                    val[bad_h if val.ndim == bad_h.ndim else np.broadcast_to(bad_h[..., None], val.shape)] = np.nan
+        out['model_cost'] = np.full(bad_h.shape, (t2 - t1) / max(n, 1))
+    if output_path is not None:
+        written = Path(json_data['postprocess'].get('output_file'))
+        out['output_path'] = written.relative_to(Path(output_path).resolve()).as_posix()
+    out['thruster_output'] = sim_results
+    return out
+
+
+def _to_host(x):
+    return x.detach().cpu().numpy() if m.is_torch(x) else np.asarray(x, dtype=np.float64)

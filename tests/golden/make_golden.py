@@ -295,6 +295,8 @@ def main():
           **{f'nan15_{k}': v for k, v in nan_q15.items()}, **{f'out15_{k}': v for k, v in out_q15.items()},
           **{f'nan30_{k}': v for k, v in nan_q3.items()}, **{f'out30_{k}': v for k, v in out_q3.items()})
 
+    _hallthruster_jl_golden(thruster)
+
     with open(OUT / 'thruster_host.json', 'w') as fd:
         json.dump({'fidelity': fid, 'convert_map': p2j, 'convert_to_julia': jd, 'convert_to_pem': back,
                    'format_twozone': fmt, 'format_gaussian': fmt_g,
@@ -303,6 +305,97 @@ def main():
                                  'FUNDAMENTAL_CHARGE': const.FUNDAMENTAL_CHARGE,
                                  'MOLECULAR_WEIGHTS': const.MOLECULAR_WEIGHTS}}, fd, indent=1)
     print('wrote thruster_host.json')
+
+
+def fake_run_simulation(json_input, jl_env=None, jl_script=None, **kwargs):
+    """What tests/sim_hallthruster.jl does to its input file, in numpy (the formulas of its lines 35-47; Julia is absent):
+    the stand-in for `run_hallthruster_jl` when the reference's `hallthruster_jl` is run here.  The output goes through
+    a JSON file and back, as it does in the reference, so that the golden values are what json.load returns."""
+    doc = json_input
+    cfg = doc['config']
+    V, Vc, md, c1 = cfg['discharge_voltage'], cfg['cathode_coupling_voltage'], cfg['anode_mass_flow_rate'], cfg['anom_model']['model']['c1']
+    nc, dom = doc['simulation']['grid']['num_cells'], cfg['domain']
+    q, mi = 1.6e-19, 2.18e-25
+    beam = (q / mi) * md
+    ceff = 1 - c1 * 2
+    Id = beam / ceff
+    v = float(np.sqrt(2 * q * (V - Vc) / mi))
+    thrust = md * v
+    z = [dom[0] + (dom[1] - dom[0]) * (i / (nc - 1)) for i in range(nc)]
+    ui = [v / (1 + float(np.exp(-100 * (zz - 0.04)))) for zz in z]
+    out = {'output': {'average': {'thrust': thrust, 'ion_current': beam, 'current_eff': ceff, 'discharge_current': Id, 'v_exh': v,
+                                  'mass_eff': 1 - c1 * 5, 'voltage_eff': 1 - c1 * 2,
+                                  'anode_eff': 0.5 * thrust ** 2 / (md * V * Id), 'ui': [ui], 'z': z}},
+           'config': cfg, 'simulation': doc['simulation'], 'postprocess': doc['postprocess']}
+    if target := doc['postprocess'].get('output_file'):
+        with open(target, 'w') as fd:
+            json.dump(out, fd)
+    return json.loads(json.dumps(out))
+
+
+def _hallthruster_jl_golden(thruster):
+    """Run the reference's own `hallthruster_jl` (thruster.py:378-512) with its Julia launcher replaced by
+    `fake_run_simulation`, and store what it returns / raises: keys, QoIs, output_path shape, the two filters."""
+    import re
+    import tempfile
+    thruster.run_hallthruster_jl = fake_run_simulation
+    cfg = {'anom_model': {'type': 'LogisticPressureShift', 'model': {'type': 'TwoZoneBohm', 'c1': 0.008, 'c2': 0.08}}, 'domain': [0, 0.08]}
+    sim = {'grid': {'type': 'EvenGrid', 'num_cells': 100}, 'duration': 1e-3, 'dt': 1e-9}
+    cases = [
+        # tests/test_thruster.py:70-94, with a dict for the device instead of the downloaded file
+        dict(name='reference_test', inputs={'V_a': 250, 'V_cc': 25, 'mdot_a': 3.5e-6}, kwargs=dict(config=cfg, simulation=sim, thruster={'name': 'SPT-100'}, postprocess={'average_start_time': 0.5e-3}), with_path=True),
+        dict(name='pem_inputs', inputs={'V_a': 300.0, 'V_cc': 32.5, 'mdot_a': 5.16e-6, 'a_1': 0.0068, 'a_2': 14.6, 'P_b': 3.5e-5, 'T_e': 1.33},
+             kwargs=dict(config={'anom_model': {'type': 'LogisticPressureShift', 'model': {'type': 'TwoZoneBohm', 'c1': 0.00625, 'c2': 0.0625}}, 'domain': [0, 0.08]},
+                         thruster=None, model_fidelity=(1, 1)), with_path=False),
+        dict(name='default_fidelity', inputs={'V_a': 280.0, 'V_cc': 20.0, 'mdot_a': 4e-6, 'a_1': 0.01}, kwargs=dict(config={'domain': [0, 0.1]}, thruster=None), with_path=True),
+        dict(name='negative_flow', inputs={'V_a': 300.0, 'V_cc': 30.0, 'mdot_a': -5e-6, 'a_1': 0.01}, kwargs=dict(config={'domain': [0, 0.08]}, thruster=None), with_path=False),
+        dict(name='shock', inputs={'V_a': 300.0, 'V_cc': 30.0, 'mdot_a': 5e-6, 'a_1': 0.01}, kwargs=dict(config={'domain': [0, 0.08]}, thruster=None, shock_threshold=0.09), with_path=False),
+        dict(name='no_shock', inputs={'V_a': 300.0, 'V_cc': 30.0, 'mdot_a': 5e-6, 'a_1': 0.01}, kwargs=dict(config={'domain': [0, 0.08]}, thruster=None, shock_threshold=0.04), with_path=False),
+        dict(name='pem_to_julia_extra', inputs={'V_a': 300.0, 'V_cc': 30.0, 'mdot_a': 5e-6, 'a_1': 0.01, 'my_in': 7.0},
+             kwargs=dict(config={'domain': [0, 0.08]}, thruster=None, pem_to_julia={'my_in': ['config', 'my', 'input'], 'v_exh': ['output', 'average', 'v_exh']}), with_path=False),
+    ]
+    out = []
+    for case in cases:
+        rec = {'name': case['name'], 'inputs': case['inputs'], 'kwargs': {k: v for k, v in case['kwargs'].items()}, 'with_path': case['with_path']}
+        with tempfile.TemporaryDirectory() as tmp:
+            kw = dict(case['kwargs'])
+            if case['with_path']:
+                kw['output_path'] = tmp
+            try:
+                res = dict(thruster.hallthruster_jl(dict(case['inputs']), **kw))
+                cost = res.pop('model_cost')
+                assert isinstance(cost, float) and cost >= 0
+                rec['keys'] = sorted(list(res) + ['model_cost'])
+                if case['with_path']:
+                    path = res.pop('output_path')
+                    rec['output_path_pattern'] = re.sub(r'_[A-Z0-9]{4}\.json$', '_XXXX.json', path)
+                    with open(Path(tmp) / path) as fd:
+                        rec['file_average_keys'] = sorted(json.load(fd)['output']['average'])
+                sim_out = res.pop('thruster_output')
+                sim_out['postprocess'].pop('output_file', None)
+                rec['thruster_output'] = sim_out
+                rec['result'] = res
+            except Exception as e:                     # noqa: BLE001 -- type and message are what is stored
+                rec['raises'] = type(e).__name__
+                rec['message'] = str(e)
+        out.append(rec)
+    # utils.load_thruster on a small device directory (the reference's own loader; hallmd.devices is not in the tree)
+    sys.path.insert(0, str(REF.parent))
+    from hallmd.utils import load_thruster
+    with tempfile.TemporaryDirectory() as tmp:
+        dev = Path(tmp) / 'MyDevice'
+        (dev / 'fields').mkdir(parents=True)
+        (dev / 'bfield.csv').write_text('z,B\n0,0.01\n')
+        (dev / 'fields' / 'extra.csv').write_text('x\n')
+        spec = {'name': 'MyDevice', 'geometry': {'channel_length': 0.025, 'inner_radius': 0.0345, 'outer_radius': 0.05},
+                'magnetic_field': {'file': 'bfield.csv'}, 'other': {'table': 'fields/extra.csv'}, 'shielded': False}
+        import yaml
+        (dev / 'thruster.yml').write_text(yaml.safe_dump(spec))
+        loaded = load_thruster(dev)
+        loaded_txt = json.dumps(loaded).replace(str(dev.resolve()), '<DEVICE>')
+    with open(OUT / 'hallthruster_jl.json', 'w') as fd:
+        json.dump({'cases': out, 'device_spec': spec, 'device_loaded': json.loads(loaded_txt)}, fd, indent=1, sort_keys=True)
+    print('wrote hallthruster_jl.json')
 
 
 if __name__ == '__main__':

@@ -1,0 +1,174 @@
+"""`hallthrusterpem_amd.models.hallthruster_jl` against what the reference's own
+`hallthruster_jl` (src/hallmd/models/thruster.py:378-512) returned and raised when tests/golden/make_golden.py ran it with
+its Julia launcher replaced by a numpy statement of tests/sim_hallthruster.jl (tests/golden/hallthruster_jl.json).
+
+CPU tests run the wrapper with that same stand-in backend (wrapper logic: formatting, conversion, filters, model_cost,
+output_path, thruster_output).  GPU tests run the default backend -- the analytic test double on the device -- one run at
+a time as tests/test_thruster.py:70-114 does, and batched."""
+import copy
+import inspect
+import json
+import re
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+sys.path.insert(0, str(GOLDEN))
+
+QOI = ('I_B0', 'I_d', 'T', 'eta_a', 'eta_c', 'eta_m', 'eta_v')
+
+
+@pytest.fixture(scope='module')
+def g():
+    with open(GOLDEN / 'hallthruster_jl.json') as fd:
+        return json.load(fd)
+
+
+def _run(case, tmp_path, **extra):
+    from hallthrusterpem_amd.models import hallthruster_jl
+    kw = copy.deepcopy(case['kwargs'])
+    if 'model_fidelity' in kw:
+        kw['model_fidelity'] = tuple(kw['model_fidelity'])
+    if case['with_path']:
+        kw['output_path'] = tmp_path
+    return hallthruster_jl(dict(case['inputs']), **kw, **extra)
+
+
+def _check_case(case, tmp_path, rel, **extra):
+    if 'raises' in case:
+        with pytest.raises(ValueError) as err:
+            _run(case, tmp_path, **extra)
+        assert case['raises'] == 'ValueError'
+        if rel == 0:
+            assert str(err.value) == case['message']
+        else:
+            assert str(err.value).split(':')[0] == case['message'].split(':')[0]
+        return
+    out = _run(case, tmp_path, **extra)
+    assert sorted(out) == case['keys']
+    assert isinstance(out['model_cost'], float) and out['model_cost'] >= 0
+    for key, want in case['result'].items():
+        got = out[key]
+        if rel == 0:
+            assert got == want, key
+        else:
+            assert np.asarray(got, dtype=np.float64) == pytest.approx(np.asarray(want, dtype=np.float64), rel=rel, abs=0), key
+    sim = copy.deepcopy(out['thruster_output'])
+    sim['postprocess'].pop('output_file', None)
+    assert sorted(sim) == sorted(case['thruster_output'])
+    assert sim['config'] == case['thruster_output']['config'] and sim['simulation'] == case['thruster_output']['simulation']
+    assert sorted(sim['output']['average']) == sorted(case['thruster_output']['output']['average'])
+    if case['with_path']:
+        assert re.sub(r'_[A-Z0-9]{4}\.json$', '_XXXX.json', out['output_path']) == case['output_path_pattern']
+        with open(tmp_path / out['output_path']) as fd:            # tests/test_thruster.py:98-102
+            data = json.load(fd)
+        assert sorted(data['output']['average']) == case['file_average_keys']
+        for key in ('thrust', 'ion_current', 'discharge_current', 'mass_eff', 'voltage_eff', 'current_eff'):
+            assert key in data['output']['average']
+
+
+def test_signature_is_the_references_plus_the_backend_hook():
+    from hallthrusterpem_amd.models import hallthruster_jl
+    names = list(inspect.signature(hallthruster_jl).parameters)
+    assert names == ['thruster_inputs', 'thruster', 'config', 'simulation', 'postprocess', 'model_fidelity', 'output_path',
+                     'version', 'pem_to_julia', 'fidelity_function', 'julia_script', 'run_kwargs', 'shock_threshold',
+                     'run_simulation']                                     # thruster.py:378-392 + the pluggable run
+    import hallthrusterpem_amd.models as models
+    assert models.__all__[:3] == ['cathode_coupling', 'hallthruster_jl', 'current_density']   # src/hallmd/models/__init__.py:15-19
+
+
+def test_wrapper_logic_against_the_reference_function(g, tmp_path):
+    """Same backend as the golden generator -> everything the wrapper adds must be identical: values, keys, messages."""
+    from make_golden import fake_run_simulation
+    for i, case in enumerate(g['cases']):
+        sub = tmp_path / str(i)
+        sub.mkdir()
+        _check_case(case, sub, rel=0, run_simulation=fake_run_simulation)
+
+
+def test_backend_receives_what_run_hallthruster_jl_would(tmp_path):
+    from hallthrusterpem_amd.models import hallthruster_jl
+    from make_golden import fake_run_simulation
+    seen = {}
+
+    def spy(json_input, jl_env=None, jl_script=None, **kwargs):
+        seen.update(jl_env=jl_env, jl_script=jl_script, kwargs=kwargs, doc=copy.deepcopy(json_input))
+        return fake_run_simulation(json_input)
+    hallthruster_jl({'V_a': 300.0, 'V_cc': 30.0, 'mdot_a': 5e-6, 'a_1': 0.01}, thruster=None, config={'domain': [0, 0.08]},
+                    version='0.18.1', julia_script='sim.jl', run_simulation=spy)
+    assert str(seen['jl_env']).endswith('.julia/environments/hallthruster_0.18.1') and seen['jl_script'] == 'sim.jl'
+    assert seen['kwargs'] == {'check': True}                                # thruster.py:473-474
+    assert seen['doc']['simulation']['grid']['num_cells'] == 200 and seen['doc']['config']['ncharge'] == 3   # model_fidelity (2, 2)
+    hallthruster_jl({'V_a': 300.0, 'V_cc': 30.0, 'mdot_a': 5e-6, 'a_1': 0.01}, thruster=None, config={'domain': [0, 0.08]},
+                    version=None, run_kwargs={'timeout': 5}, run_simulation=spy)
+    assert seen['jl_env'] is None and seen['kwargs'] == {'timeout': 5}
+
+
+def test_load_thruster_matches_the_reference_loader(g, tmp_path):
+    import yaml
+    from hallthrusterpem_amd.models import hallthruster_jl
+    from hallthrusterpem_amd.utils import load_thruster
+    from make_golden import fake_run_simulation
+    dev = tmp_path / 'MyDevice'
+    (dev / 'fields').mkdir(parents=True)
+    (dev / 'bfield.csv').write_text('z,B\n0,0.01\n')
+    (dev / 'fields' / 'extra.csv').write_text('x\n')
+    (dev / 'thruster.yml').write_text(yaml.safe_dump(g['device_spec']))
+    got = json.loads(json.dumps(load_thruster(dev)).replace(str(dev.resolve()), '<DEVICE>'))
+    assert got == g['device_loaded']
+    (dev / 'thruster.json').write_text(json.dumps(g['device_spec']))
+    assert load_thruster(dev, 'thruster.json') == load_thruster(dev)
+    (dev / 'thruster.txt').write_text('x')
+    with pytest.raises(ValueError):
+        load_thruster(dev, 'thruster.txt')
+    # a device directory as the `thruster` argument, as pem_v0_SPT-100.yml:65 passes it
+    out = hallthruster_jl({'V_a': 300.0, 'V_cc': 30.0, 'mdot_a': 5e-6, 'a_1': 0.01}, thruster=dev, config={'domain': [0, 0.08]},
+                          run_simulation=fake_run_simulation, output_path=tmp_path)
+    assert out['thruster_output']['config']['thruster']['name'] == 'MyDevice'
+    assert out['output_path'].startswith('hallthruster_jl_MyDevice_300V_5.0e-06kg_s_')
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the default backend: the analytic test double on the GPU
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_default_backend_one_run_at_a_time(g, tmp_path):
+    """tests/test_thruster.py:70-114 and the other golden cases through pem_thruster_f64 + pem_thruster_uion_f64_dev.
+    Arithmetic of sim_hallthruster.jl:35-47 is +,-,*,/,sqrt (bit-identical) and one exp per cell (a few ulp)."""
+    for i, case in enumerate(g['cases']):
+        sub = tmp_path / str(i)
+        sub.mkdir()
+        _check_case(case, sub, rel=1e-14)
+    out = _run(g['cases'][0], tmp_path)
+    for key in ('T', 'I_B0', 'I_d', 'u_ion', 'u_ion_coords'):            # tests/test_thruster.py:95-96
+        assert key in out
+    assert isinstance(out['T'], float) and isinstance(out['u_ion'], list) and len(out['u_ion']) == 100
+    json.dumps(out['thruster_output'])                                    # what the reference got from json.load is serialisable
+
+
+@pytest.mark.gpu
+def test_default_backend_batched_equals_thruster_analytic():
+    import torch
+    from hallthrusterpem_amd.models import hallthruster_jl, thruster_analytic
+    rng = np.random.default_rng(5)
+    n = 1000
+    x = {'V_a': rng.uniform(200, 400, n), 'V_cc': rng.uniform(0, 60, n), 'mdot_a': rng.uniform(2e-6, 7e-6, n), 'a_1': 10 ** rng.uniform(-2.5, -1, n)}
+    cfg = {'domain': [0, 0.08]}
+    want = thruster_analytic(x, num_cells=150, domain=(0, 0.08))
+    for make in (lambda v: v, lambda v: torch.from_numpy(v).cuda()):
+        out = hallthruster_jl({k: make(v) for k, v in x.items()}, thruster=None, config=cfg, model_fidelity=(1, 0))
+        for key in QOI + ('u_ion', 'u_ion_coords'):
+            got = out[key].cpu().numpy() if hasattr(out[key], 'cpu') else np.asarray(out[key])
+            assert np.array_equal(got, want[key]), key                   # bit for bit: the same kernels
+        assert out['model_cost'].shape == (n,) and 'errors' not in out
+        assert out['thruster_output']['simulation']['grid']['num_cells'] == 150
+    # the filters in a batch: the samples the reference would raise for come back as NaN with their message
+    x['mdot_a'][[3, 500]] *= -1
+    out = hallthruster_jl(x, thruster=None, config=cfg, model_fidelity=(1, 0))
+    assert sorted(out['errors']) == [3, 500] and out['errors'][3].startswith('Exception due to non-physical case')
+    assert np.isnan(out['T'][[3, 500]]).all() and np.isnan(out['u_ion'][3]).all() and np.isfinite(np.delete(out['T'], [3, 500])).all()
+    out = hallthruster_jl({k: np.abs(v) for k, v in x.items()}, thruster=None, config=cfg, model_fidelity=(1, 0), shock_threshold=0.09)
+    assert len(out['errors']) == n and out['errors'][0].startswith('Exception due to shock-like behavior')
