@@ -3,21 +3,36 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one batch of synthetic Monte-Carlo samples already resident in HBM:
-a single `pem_coupled_f64_dev` launch over this rank's shard (BASELINE.json configs[2]: 1e7 coupled samples
-sharded over 8 GPUs = 1.25e6 samples per GPU; the same per-GPU shard is used at every N, so scaling is weak),
-followed at N > 1 by one RCCL all-gather of the reduced QoIs (V_cc, div_angle, T_c), the path's only exchange.
+One "step" = one pass of the hot path over one batch of synthetic Monte-Carlo samples already resident in HBM: this
+rank's shard of BASELINE.json configs[2] (1e7 coupled samples sharded over 8 GPUs = 1.25e6 samples per GPU; the same
+per-GPU shard at every N, so scaling is weak) evaluated by `pem_coupled_f64_dev`, followed at N > 1 by the path's only
+exchange, the RCCL all-gather of the reduced QoIs (V_cc, div_angle, T_c).  At N > 1 the shard is cut into `--chunks`
+pieces and the all-gather of piece k runs beside the evaluation of piece k+1 (hallthrusterpem_amd.distributed.
+ChunkedGather), so a single campaign overlaps its own exchange; `--gather once` is the one-collective-per-campaign
+schedule, `--gather none` skips the exchange, `--gather full` moves the 91-point profiles.
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (python -m torch.distributed.run,
+as a child process, before anything touches the GPU); under torch.distributed.run it reads RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* as usual.  After the timed region every rank checks the gathered QoIs of every other rank bit for
+bit against a local re-evaluation of that rank's seeded inputs and fails loudly on a mismatch.
 
 Prints ONE JSON line on rank 0 with the fields the driver expects plus
-  "roofline":     the coupled kernel against the HBM roofline -- achieved = 872 algorithmic bytes per
-                  evaluation x samples per launch / the kernel's mean duration, measured
-                  here with HIP events on the stream the kernel runs on (torch's current stream);
-  "cpu_baseline": the CPU oracle (a C restatement of the reference's NumPy path, OpenMP) timed on this host on
-                  a bounded sample of the same workload -- reported for context, not a target.
+  "roofline":     the coupled kernel against the HBM roofline -- achieved = 872 algorithmic bytes per evaluation
+                   x samples per launch / the kernel's mean duration, measured here with HIP
+                  events on the stream the kernel runs on (torch's current stream); `traffic` is NOT measured in this
+                  run: it is the committed rocprofv3 --pmc result for the same launch size (`traffic_source` says so);
+  "cpu_baseline": the CPU oracle (a C restatement of the reference's NumPy path, OpenMP) timed on this host on a
+                  bounded sample of the same workload -- reported for context, not a target -- with the reference's own
+                  NumPy rate from BASELINE.md (measured in the build container, not on this host) beside it;
+  config.full_config (N = 1): the whole 1e7-sample configs[2] campaign as ONE launch on this GPU, measured in the
+                  same run (8.7 GB of algorithmic traffic per pass).
+  --fp32 adds the config-5 report: the fp32-arithmetic reduced-QoI kernel against the fp64 one on identical inputs.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -27,6 +42,8 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 SAMPLES_PER_GPU = 1_250_000    # BASELINE.json configs[2]: 1e7 coupled samples / 8 GPUs
+FULL_CONFIG_SAMPLES = 10_000_000
+REFERENCE_NUMPY_EVALS_PER_S = 1.4e5   # the reference's NumPy path, coupled, one core, build container
 
 
 def synth_inputs(batch, seed, rank):
@@ -34,24 +51,27 @@ def synth_inputs(batch, seed, rank):
     import torch
     g = torch.Generator(device=batch.device)
     g.manual_seed(seed * 1000 + rank)
-    u = torch.rand((15, batch.n), dtype=torch.float64, device=batch.device, generator=g)
-    x = batch.inputs
-    x[0] = 10 ** (u[0] * 4 - 8)                  # P_b      Torr, log-uniform over the domain (yml:9-17)
-    x[1] = u[1] * 200 + 200                      # V_a      V
-    x[2] = u[2] * 4 + 1                          # T_e      eV
-    x[3] = u[3] * 60                             # V_vac    V
-    x[4] = u[4] * 90e-6 + 10e-6                  # Pstar    Torr
-    x[5] = u[5] * 90e-6 + 10e-6                  # P_T      Torr
-    x[6] = u[6] * 5e-6 + 2e-6                    # mdot_a   kg/s
-    x[7] = 10 ** (u[7] * 1.5 - 2.5)              # a_1      LogUniform(0.00316, 0.1)
-    x[8] = u[8]                                  # c0
-    x[9] = u[9] * 0.8 + 0.1                      # c1
-    x[10] = u[10] * 30 - 15                      # c2
-    x[11] = u[11] * (1.570796 - 0.2) + 0.2       # c3
-    x[12] = 10 ** (u[12] * 4 + 18)               # c4
-    x[13] = 10 ** (u[13] * 4 + 14)               # c5
-    x[14] = u[14] * 7e-20 + 51e-20               # sigma_cex
-    del u
+    chunk = 1 << 21                                 # bounded temporaries for the 1e7-sample campaign
+    for lo in range(0, batch.n, chunk):
+        hi = min(batch.n, lo + chunk)
+        u = torch.rand((15, hi - lo), dtype=torch.float64, device=batch.device, generator=g)
+        x = batch.inputs[:, lo:hi]
+        x[0] = 10 ** (u[0] * 4 - 8)                  # P_b      Torr, log-uniform over the domain (yml:9-17)
+        x[1] = u[1] * 200 + 200                      # V_a      V
+        x[2] = u[2] * 4 + 1                          # T_e      eV
+        x[3] = u[3] * 60                             # V_vac    V
+        x[4] = u[4] * 90e-6 + 10e-6                  # Pstar    Torr
+        x[5] = u[5] * 90e-6 + 10e-6                  # P_T      Torr
+        x[6] = u[6] * 5e-6 + 2e-6                    # mdot_a   kg/s
+        x[7] = 10 ** (u[7] * 1.5 - 2.5)              # a_1      LogUniform(0.00316, 0.1)
+        x[8] = u[8]                                  # c0
+        x[9] = u[9] * 0.8 + 0.1                      # c1
+        x[10] = u[10] * 30 - 15                      # c2
+        x[11] = u[11] * (1.570796 - 0.2) + 0.2       # c3
+        x[12] = 10 ** (u[12] * 4 + 18)               # c4
+        x[13] = 10 ** (u[13] * 4 + 14)               # c5
+        x[14] = u[14] * 7e-20 + 51e-20               # sigma_cex
+        del u
 
 
 def host_cpu_share():
@@ -89,7 +109,10 @@ def cpu_baseline(target_seconds=2.5):
     assert np.isfinite(out['V_cc']).all()
     return {'value': n / best, 'unit': 'evals/s', 'cores': threads, 'kind': 'port',
             'sample': f'{n} coupled samples (same priors, fp64, 91 angles, full profile), best of 3 runs: '
-                      f'{best:.2f} s wall on {threads} OpenMP threads'}
+                      f'{best:.2f} s wall on {threads} OpenMP threads',
+            'reference_numpy': {'value': REFERENCE_NUMPY_EVALS_PER_S, 'unit': 'evals/s', 'cores': 1,
+                                'source': 'BASELINE.md section 2: hallmd cathode_coupling + current_density (NumPy/SciPy), 1e5 samples, '
+                                          'measured in the build container (8 vCPU Xeon @2.1 GHz); the reference cannot travel to this host'}}
 
 
 def read_committed_traffic(n):
@@ -98,10 +121,68 @@ def read_committed_traffic(n):
         try:
             rec = json.loads(f.read_text())
             if int(rec.get('samples_per_launch', -1)) == int(n):
-                return float(rec['hbm_bytes_per_launch'])
+                return float(rec['hbm_bytes_per_launch']), f.name
         except Exception:
             continue
-    return None
+    return None, None
+
+
+def event_times(fn, reps):
+    """mean / min duration (ms) of `fn` between HIP events on torch's current stream"""
+    import torch
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in evs:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b) for a, b in evs)
+    return sum(ms) / len(ms), ms[0]
+
+
+def full_config_pass(n, seed, lanes):
+    """configs[2] whole: n = 1e7 coupled samples as one launch on this GPU (N = 1 only)."""
+    import torch
+    from hallthrusterpem_amd.batch import CoupledBatch
+    b = CoupledBatch(n, profile=True, thruster_qoi=False)
+    synth_inputs(b, seed, 0)
+    for _ in range(2):
+        b.run()
+    torch.cuda.synchronize()
+    reps = 10
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        b.run()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / reps
+    mean_ms, min_ms = event_times(b.run, reps)
+    rec = {'samples': n, 'passes_timed': reps, 'ms_per_pass': 1e3 * wall, 'value': n / wall, 'unit': 'evals/s',
+           'kernel_ms_mean': mean_ms, 'kernel_ms_min': min_ms, 'bytes_per_launch': b.bytes_per_eval * n,
+           'achieved_GBs': b.bytes_per_eval * n / (mean_ms * 1e-3) / 1e9,
+           'frac_of_peak': b.bytes_per_eval * n / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           'invalid_fraction': float(b.invalid.float().mean().item())}
+    del b
+    torch.cuda.empty_cache()
+    return rec
+
+
+def fp32_report(n, seed):
+    """config 5's tolerance check: the fp32-arithmetic reduced-QoI kernel against the fp64 one on identical inputs."""
+    from hallthrusterpem_amd.fp32 import compare_with_fp64
+    return compare_with_fp64(n, lambda batch: synth_inputs(batch, seed, 0))
+
+
+def spawn_ranks(args_list, n):
+    """`bench.py --gpus N` outside torch.distributed.run: start the N ranks as a child process (nothing in THIS process
+    has touched the GPU) and pass its stdout -- the one JSON line of rank 0 -- and exit code through."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), str(Path(__file__).resolve()), *args_list]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -111,14 +192,25 @@ def main():
     ap.add_argument('--warmup', type=int, default=30)
     ap.add_argument('--samples-per-gpu', type=int, default=SAMPLES_PER_GPU)
     ap.add_argument('--lanes', type=int, default=0, help='lanes per sample of the kernel (0 = library default)')
-    ap.add_argument('--gather', choices=['qoi', 'full', 'none'], default='qoi',
-                    help='what the N>1 all-gather moves: reduced QoIs (24 B/sample), full profiles, or nothing')
+    ap.add_argument('--gather', choices=['qoi', 'once', 'full', 'none'], default='qoi',
+                    help='N>1 exchange: qoi = reduced QoIs (24 B/sample) in --chunks overlapped pieces; once = the same in one '
+                         'collective per campaign; full = the 91-point profiles; none = no exchange')
+    ap.add_argument('--chunks', type=int, default=4, help='pieces a shard is cut into at N>1 so that the all-gather of piece k '
+                                                          'overlaps the evaluation of piece k+1')
     ap.add_argument('--no-profile', action='store_true', help='reduced-QoI mode: never write j_ion (144 B/eval)')
     ap.add_argument('--mixed', action='store_true', help='fp64 arithmetic, fp32 storage of the profile (508 B/eval)')
+    ap.add_argument('--fp32', action='store_true', help='add the fp32-arithmetic reduced-QoI kernel vs fp64 report (config 5)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--full-config-samples', type=int, default=FULL_CONFIG_SAMPLES,
+                    help='N=1: also run the whole configs[2] campaign as one launch of this many samples (0 = skip)')
     ap.add_argument('--seed', type=int, default=2)
     ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL; default) or gloo (rehearsal on one GPU)')
+    ap.add_argument('--oversubscribe', action='store_true',
+                    help='rehearsal only: allow more ranks than GPUs (ranks then share devices; never a measurement)')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(spawn_ranks(sys.argv[1:], args.gpus))
 
     # stdout carries exactly one JSON line: everything libraries print meanwhile (RCCL writes its version banner to
     # stdout under NCCL_DEBUG=VERSION) is sent to stderr by pointing fd 1 at fd 2 until the line is ready
@@ -130,13 +222,19 @@ def main():
     import torch.distributed as dist
     from hallthrusterpem_amd import _lib
     from hallthrusterpem_amd.batch import CoupledBatch
+    from hallthrusterpem_amd.distributed import ChunkedGather
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
-    local_dev = local_rank % max(1, torch.cuda.device_count())   # == local_rank on a real multi-GPU node
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit('bench.py: no HIP device visible (there is no CPU path)')
+    if world > ndev and not args.oversubscribe:
+        raise SystemExit(f'bench.py: {world} ranks but {ndev} GPU(s) visible: one process per GPU (--oversubscribe is for rehearsals)')
+    local_dev = local_rank % ndev          # == local_rank unless --oversubscribe
     torch.cuda.set_device(local_dev)
     # PEM_BENCH_FORCE_DIST=1: take the N > 1 code path (process group, overlapped all-gather) with a single rank,
     # to rehearse the RCCL calls on a one-GPU box
@@ -158,38 +256,41 @@ def main():
     # outputs per evaluation exactly as SURVEY section 8d counts them: V_cc, j_ion[91], div_angle, T_c (+ invalid flag)
     batch = CoupledBatch(n, profile=not args.no_profile, mixed=args.mixed, thruster_qoi=False)
     synth_inputs(batch, args.seed, rank)
-    # N > 1: the all-gather of step i runs beside the evaluation of step i+1 (RCCL works on its own stream):
-    # two batches alternate so a QoI buffer is not rewritten while it is still being sent.
-    nbuf = 2 if (multi and args.gather != 'none') else 1
-    batches = [batch]
-    for _ in range(nbuf - 1):
-        b2 = CoupledBatch(n, profile=not args.no_profile, mixed=args.mixed, thruster_qoi=False)
-        b2.inputs.copy_(batch.inputs)
-        batches.append(b2)
-    gathered, pending = [], [None] * nbuf
-    for b in batches:
-        if multi and args.gather == 'qoi':
-            gathered.append(torch.empty((world * b.qoi.shape[0], n), dtype=torch.float64, device=b.device))
-        elif multi and args.gather == 'full':
-            gathered.append(torch.empty((world * n, b.j_ion.shape[1]), dtype=b.j_ion.dtype, device=b.device))
-    counter = [0]
+
+    # N > 1: the shard in `chunks` pieces, each piece's QoIs in its own send buffer, its all-gather beside the next piece
+    gather_on = multi and args.gather != 'none'
+    chunks = 1 if (not gather_on or args.gather in ('once', 'full')) else max(1, args.chunks)
+    pipe = ChunkedGather(n, 3, chunks, batch.device, gather=gather_on and args.gather != 'full') if multi else None
+    full_recv = torch.empty((world * n, batch.j_ion.shape[1]), dtype=batch.j_ion.dtype, device=batch.device) \
+        if (gather_on and args.gather == 'full' and batch.profile) else None
+    pending_full = [None]
+    use_gather = [True]
+
+    def evaluate(first, count, out_rows):
+        batch.run(first=first, count=count, qoi_out=out_rows)
 
     def step():
-        i = counter[0] % nbuf
-        counter[0] += 1
-        if pending[i] is not None:
-            pending[i].wait()               # stream-level: this buffer's previous gather must have read it
-            pending[i] = None
-        batches[i].run()
-        if gathered:
-            src = batches[i].qoi if args.gather == 'qoi' else batches[i].j_ion
-            pending[i] = dist.all_gather_into_tensor(gathered[i], src, async_op=True)
+        if pipe is None:
+            batch.run()
+            return
+        if not use_gather[0]:
+            for first, count in pipe.bounds:
+                batch.run(first=first, count=count)
+            return
+        if full_recv is not None:
+            if pending_full[0] is not None:
+                pending_full[0].wait()
+            batch.run()
+            pending_full[0] = dist.all_gather_into_tensor(full_recv, batch.j_ion, async_op=True)
+        else:
+            pipe.step(evaluate)
 
     def drain():
-        for i, w in enumerate(pending):
-            if w is not None:
-                w.wait()
-                pending[i] = None
+        if pipe is not None:
+            pipe.drain()
+        if pending_full[0] is not None:
+            pending_full[0].wait()
+            pending_full[0] = None
 
     def fence():
         drain()
@@ -216,26 +317,40 @@ def main():
     elapsed = timed(args.steps)
     # N > 1: also the gather-free rate of the same shards (reported beside `value`, SURVEY.md section 8e "report both")
     elapsed_nogather = None
-    if gathered:
-        saved, gathered = gathered, []
+    if gather_on:
+        use_gather[0] = False
         elapsed_nogather = timed(args.steps)
-        gathered = saved
+        use_gather[0] = True
+
+    # N > 1: what arrived is what was sent -- every rank re-evaluates every rank's seeded shard and compares bit for bit
+    verified = None
+    if gather_on and full_recv is None:
+        step()
+        got = pipe.assemble()                                   # [3][world * n], global order
+        ok = True
+        for q in range(pipe.world):
+            synth_inputs(batch, args.seed, q)
+            batch.run()
+            torch.cuda.synchronize()
+            ok = ok and torch.equal(got[:, q * n:(q + 1) * n].view(torch.int64), batch.qoi.view(torch.int64))
+        synth_inputs(batch, args.seed, rank)
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=batch.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        verified = bool(flag.item())
+        if not verified:
+            raise SystemExit(f'bench.py: rank {rank}: gathered QoIs differ from a local re-evaluation of the ranks\' shards')
 
     # kernel-only duration: HIP events on the launch stream around each launch (outside the timed region)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(args.steps, 50))]
-    for a, b in evs:
-        a.record()
-        batch.run()
-        b.record()
-    torch.cuda.synchronize()
-    kern_ms = sorted(a.elapsed_time(b) for a, b in evs)
-    kern_mean_ms = sum(kern_ms) / len(kern_ms)
+    kern_mean_ms, kern_min_ms = event_times(batch.run, min(args.steps, 50))
     frac_invalid = float(batch.invalid.float().mean().item())
 
     if rank == 0:
         bytes_per_launch = batch.bytes_per_eval * n
         achieved = bytes_per_launch / (kern_mean_ms * 1e-3) / 1e9
-        traffic = read_committed_traffic(n) if not (args.no_profile or args.mixed) else None
+        traffic, traffic_file = read_committed_traffic(n) if not (args.no_profile or args.mixed) else (None, None)
+        gather_desc = {'qoi': f'reduced QoIs (24 B/sample), {len(pipe.bounds) if pipe else 1} chunks per step, each all-gather overlapped with the next chunk\'s evaluation',
+                       'once': 'reduced QoIs (24 B/sample), one all-gather per step, overlapped with the next step',
+                       'full': '91-point profiles, one all-gather per step, overlapped with the next step'}.get(args.gather, 'none')
         line = {
             'metric': 'coupled PEM-v0 model evals/sec', 'value': world * n * args.steps / elapsed, 'unit': 'evals/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
@@ -244,16 +359,25 @@ def main():
                                    'BASELINE configs[2] shard (1e7 samples / 8 GPUs), 91 angles, R=1 at 1.0 m',
                        'samples_per_gpu': n, 'global_samples_per_step': world * n, 'seed': args.seed,
                        'TORR_2_PA': 133.322, 'lanes_per_sample': lanes, 'profile_written': not args.no_profile,
-                       'gather': (args.gather + ', overlapped with the next step') if (multi and args.gather != 'none') else 'none',
+                       'gather': gather_desc if gather_on else 'none',
+                       'gathered_qoi_verified': verified,
                        'value_without_gather': (world * n * args.steps / elapsed_nogather) if elapsed_nogather else None,
                        'parallelism': f'sample-shard x{world}',
                        'invalid_fraction': frac_invalid},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'traffic_source': (f'replayed from profiles/{traffic_file} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this '
+                                            f'launch size, gfx950 corrections applied); not measured in this run') if traffic else None,
                          'kernel': 'plume_r1_kernel<L,COUPLED,JMODE>', 'kernel_ms_mean': kern_mean_ms,
-                         'kernel_ms_min': kern_ms[0], 'bytes_per_eval': batch.bytes_per_eval,
+                         'kernel_ms_min': kern_min_ms, 'bytes_per_eval': batch.bytes_per_eval,
                          'bytes_per_launch': bytes_per_launch},
         }
+        if world == 1 and not multi and args.full_config_samples > 0 and not (args.no_profile or args.mixed):
+            del batch
+            torch.cuda.empty_cache()
+            line['config']['full_config'] = full_config_pass(args.full_config_samples, args.seed, lanes)
+        if args.fp32 and world == 1:
+            line['fp32'] = fp32_report(n, args.seed)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
         else:

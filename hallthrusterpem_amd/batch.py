@@ -47,6 +47,19 @@ class CoupledBatch:
         self._out_ptrs = [p(self.qoi[0]), p(self.I_B0) if self.I_B0 is not None else None,
                           p(self.T) if self.T is not None else None, p(self.j_ion) if self.profile else None,
                           p(self.qoi[1]), p(self.qoi[2]), p(self.invalid)]
+        # bytes per sample behind each output pointer: what `run(first, count)` advances them by
+        jb = (4 if self.mixed else 8) * _lib.NANGLE
+        self._out_strides = [8, 8, 8, jb, 8, 8, 1]
+
+    def _range_ptrs(self, first: int, qoi_out=None):
+        """Pointers of samples first.. of every array; `qoi_out` ([3][>= count] tensor) redirects V_cc / div_angle / T_c
+        (the multi-GPU pipeline writes each chunk's QoIs into its own contiguous send buffer)."""
+        off = lambda ptr, nbytes: None if ptr is None else C.c_void_p(ptr.value + nbytes)   # noqa: E731
+        ins = [off(q, 8 * first) for q in self._in_ptrs]
+        outs = [off(q, st * first) for q, st in zip(self._out_ptrs, self._out_strides)]
+        if qoi_out is not None:
+            outs[0], outs[4], outs[5] = (C.c_void_p(qoi_out[i].data_ptr()) for i in range(3))
+        return ins, outs
 
     def set_inputs(self, values: dict):
         """Copy a dict of arrays/tensors (keys = COUPLED_INPUTS) into the batch."""
@@ -54,12 +67,22 @@ class CoupledBatch:
         for i, k in enumerate(COUPLED_INPUTS):
             self.inputs[i].copy_(torch.as_tensor(values[k], dtype=torch.float64).to(self.device).expand(self.n))
 
-    def run(self, stream=None):
-        """Enqueue one coupled evaluation of the whole batch (asynchronous)."""
+    def run(self, stream=None, first: int = 0, count: int | None = None, qoi_out=None):
+        """Enqueue one coupled evaluation (asynchronous) of the whole batch, or of samples first .. first+count-1.
+        `first` must be even: the profile rows of a range then start 16-byte aligned, as the kernel's stores require."""
         import torch
         s = torch.cuda.current_stream(self.device) if stream is None else stream
         fn = _lib.load().pem_coupled_mixed_dev if self.mixed else _lib.load().pem_coupled_f64_dev
-        rc = fn(self.n, constants.TORR_2_PA, self.radius, *self._in_ptrs, *self._out_ptrs, C.c_void_p(s.cuda_stream))
+        if first == 0 and count is None and qoi_out is None:
+            ins, outs, count = self._in_ptrs, self._out_ptrs, self.n
+        else:
+            count = self.n - first if count is None else int(count)
+            if first < 0 or count < 0 or first + count > self.n or (first & 1 and self.mixed):
+                raise ValueError(f'range [{first}, {first + count}) does not fit a batch of {self.n} samples')
+            if first & 1:
+                raise ValueError('a range must start at an even sample (16-byte aligned profile rows)')
+            ins, outs = self._range_ptrs(int(first), qoi_out)
+        rc = fn(count, constants.TORR_2_PA, self.radius, *ins, *outs, C.c_void_p(s.cuda_stream))
         _lib.check(rc)
 
     def run_mc(self, design, first_index: int = 0, write_inputs: bool = False, swap_dim: int = -1, stream=None):

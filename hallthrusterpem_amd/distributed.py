@@ -45,6 +45,79 @@ def all_gather_rows(local, n_total: int, group=None):
     return out
 
 
+def chunk_bounds(n: int, chunks: int, align: int = 64):
+    """Cut one rank's shard of `n` samples into at most `chunks` contiguous pieces whose starts are multiples of `align`
+    (whole 64-sample kernel tiles; 16-byte aligned profile rows).  Returns [(first, count), ...]; pieces differ by at
+    most `align` samples and none is empty."""
+    if n <= 0:
+        return []
+    chunks = max(1, min(int(chunks), (n + align - 1) // align))
+    tiles = (n + align - 1) // align
+    edges = [min(n, ((k * tiles) // chunks) * align) for k in range(chunks)] + [n]
+    return [(a, b - a) for a, b in zip(edges, edges[1:]) if b > a]
+
+
+class ChunkedGather:
+    """One rank's side of a forward-UQ campaign whose QoI all-gather overlaps its own evaluation.
+
+    The shard is cut into K chunks (`chunk_bounds`).  `step(evaluate)` walks them: chunk k is evaluated into its own
+    contiguous `[rows][width]` send buffer, its `all_gather_into_tensor` is issued asynchronously (RCCL orders it after
+    the kernels already enqueued on the current stream and runs it on its own stream), and chunk k+1 is enqueued at
+    once -- so the xGMI transfer of chunk k runs beside the evaluation of chunk k+1 INSIDE one campaign, not only across
+    repeated campaigns.  K = 1 is the plain "evaluate everything, gather once" schedule.  Before a chunk's buffers are
+    reused (next step) the previous collective on them is waited for at stream level.
+
+    evaluate(first, count, out_rows): enqueue the model for local samples first .. first+count-1, writing the gathered
+    QoIs (e.g. V_cc, div_angle, T_c) to out_rows[i][:count].  Nothing here knows what the model is."""
+
+    def __init__(self, n_local: int, rows: int, chunks: int, device, dtype=None, group=None, gather: bool = True):
+        import torch
+        import torch.distributed as dist
+        self.group = group
+        self.world = dist.get_world_size(group) if (gather and dist.is_initialized()) else 1
+        self.rank = dist.get_rank(group) if (gather and dist.is_initialized()) else 0
+        self.gather = bool(gather) and dist.is_initialized()
+        self.n_local, self.rows = int(n_local), int(rows)
+        self.bounds = chunk_bounds(self.n_local, chunks)
+        self.width = max((c for _, c in self.bounds), default=0)
+        dtype = torch.float64 if dtype is None else dtype
+        k = len(self.bounds)
+        self.send = torch.zeros((k, self.rows, self.width), dtype=dtype, device=device)
+        # concatenation layout (world * rows) per chunk: accepted by both the RCCL and the gloo backends
+        self.recv = torch.zeros((k, self.world * self.rows, self.width), dtype=dtype, device=device) if self.gather else None
+        self.pending = [None] * k
+
+    def step(self, evaluate):
+        import torch.distributed as dist
+        for k, (first, count) in enumerate(self.bounds):
+            if self.pending[k] is not None:
+                self.pending[k].wait()          # stream-level: the previous gather of this chunk has read its buffer
+                self.pending[k] = None
+            evaluate(first, count, self.send[k])
+            if self.gather:
+                self.pending[k] = dist.all_gather_into_tensor(self.recv[k], self.send[k], group=self.group, async_op=True)
+
+    def drain(self):
+        for k, w in enumerate(self.pending):
+            if w is not None:
+                w.wait()
+                self.pending[k] = None
+
+    def assemble(self):
+        """[rows][world * n_local] in global sample order (rank r owns [r n_local, (r+1) n_local)) from the last step."""
+        import torch
+        self.drain()
+        out = torch.empty((self.rows, self.world * self.n_local), dtype=self.send.dtype, device=self.send.device)
+        for k, (first, count) in enumerate(self.bounds):
+            if self.gather:
+                piece = self.recv[k].view(self.world, self.rows, self.width)
+                for r in range(self.world):
+                    out[:, r * self.n_local + first: r * self.n_local + first + count] = piece[r, :, :count]
+            else:
+                out[:, first:first + count] = self.send[k, :, :count]
+        return out
+
+
 def evaluate_sharded(n_total: int, make_inputs: Callable[[int, int], Dict], evaluate: Callable[[Dict], Dict],
                      qoi=('V_cc', 'div_angle', 'T_c'), group=None):
     """Forward UQ over `n_total` samples on all ranks of `group`.

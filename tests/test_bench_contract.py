@@ -14,7 +14,7 @@ ROOT = Path(__file__).resolve().parents[1]
 pytestmark = pytest.mark.gpu
 KEYS = {'metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
         'dtype', 'data', 'config', 'roofline', 'cpu_baseline'}
-SMALL = ['--steps', '4', '--warmup', '2', '--samples-per-gpu', '131072']
+SMALL = ['--steps', '4', '--warmup', '2', '--samples-per-gpu', '131072', '--full-config-samples', '0']
 
 
 def _one_json_line(stdout: str) -> dict:
@@ -35,6 +35,24 @@ def test_single_gpu_line():
     assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
     assert r['bytes_per_eval'] == 872 and line['config']['samples_per_gpu'] == 131072
     assert abs(line['value'] - 131072 * 4 / (line['ms_per_step'] * 4e-3)) / line['value'] < 1e-9
+    assert 'full_config' not in line['config'] and line['config']['gather'] == 'none'
+    if r['traffic'] is not None:
+        assert 'not measured in this run' in r['traffic_source']
+
+
+def test_single_gpu_line_carries_the_whole_config():
+    """configs[2] is 1e7 coupled samples: at N = 1 the line also carries that campaign as one launch, measured in the same
+    run (here at a reduced size so that the test stays short; the driver's run uses the default 1e7)."""
+    out = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--steps', '4', '--warmup', '2', '--full-config-samples', '2000000'],
+                         capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = _one_json_line(out.stdout)
+    fc = line['config']['full_config']
+    assert fc['samples'] == 2_000_000 and fc['bytes_per_launch'] == 872 * 2_000_000 and fc['value'] > 1e9
+    assert abs(fc['frac_of_peak'] - fc['achieved_GBs'] / 8000.0) < 1e-12 and 0.3 < fc['frac_of_peak'] < 1.0
+    assert line['config']['samples_per_gpu'] == 1_250_000 and line['roofline']['traffic_source'].startswith('replayed from profiles/')
+    cb = line['cpu_baseline']
+    assert cb['kind'] == 'port' and cb['reference_numpy']['value'] == 1.4e5 and cb['reference_numpy']['cores'] == 1
 
 
 def test_two_ranks_through_torch_distributed_run():
@@ -43,13 +61,35 @@ def test_two_ranks_through_torch_distributed_run():
         port = s.getsockname()[1]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), str(ROOT / 'bench.py'), '--gpus', '2', *SMALL, '--dist-backend', 'gloo']
+           '--master-port', str(port), str(ROOT / 'bench.py'), '--gpus', '2', *SMALL, '--dist-backend', 'gloo', '--oversubscribe']
     out = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     line = _one_json_line(out.stdout)
     assert line['n_gpus'] == 2 and line['config']['global_samples_per_step'] == 2 * 131072
-    assert line['config']['gather'].startswith('qoi') and line['config']['value_without_gather'] >= line['value'] * 0.5
+    assert line['config']['gather'].startswith('reduced QoIs (24 B/sample), 4 chunks') and line['config']['value_without_gather'] >= line['value'] * 0.5
     assert line['cpu_baseline'] is None and line['config']['parallelism'] == 'sample-shard x2'
+    # after the overlapped loop every rank compared what it received from every rank with a local re-evaluation
+    assert line['config']['gathered_qoi_verified'] is True
+
+
+@pytest.mark.parametrize('gather', ['once', 'qoi'])
+def test_gpus_flag_alone_starts_the_ranks(gather):
+    """`python bench.py --gpus 2` the way the driver calls `--gpus 1`: no torch.distributed.run around it -- bench.py
+    starts the ranks itself, as a child process, before it touches the GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--gpus', '2', *SMALL, '--dist-backend', 'gloo', '--oversubscribe',
+                          '--gather', gather, '--chunks', '3'], capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = _one_json_line(out.stdout)
+    assert line['n_gpus'] == 2 and line['config']['gathered_qoi_verified'] is True
+    assert ('3 chunks' in line['config']['gather']) == (gather == 'qoi')
+
+
+def test_more_ranks_than_gpus_is_refused():
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--gpus', '2', *SMALL, '--dist-backend', 'gloo'],
+                         capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
+    assert out.returncode != 0 and 'one process per GPU' in out.stderr and not out.stdout.strip()
 
 
 def test_rccl_code_path_with_one_rank():
@@ -65,4 +105,5 @@ def test_rccl_code_path_with_one_rank():
                          cwd=ROOT, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     line = _one_json_line(out.stdout)
-    assert line['n_gpus'] == 1 and line['config']['gather'].startswith('qoi') and line['config']['value_without_gather'] > 0
+    assert line['n_gpus'] == 1 and line['config']['gather'].startswith('reduced QoIs') and line['config']['value_without_gather'] > 0
+    assert line['config']['gathered_qoi_verified'] is True

@@ -18,7 +18,7 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / 'tests'))
 
-from hallthrusterpem_amd.distributed import all_gather_rows, evaluate_sharded, max_shard, shard_bounds  # noqa: E402
+from hallthrusterpem_amd.distributed import ChunkedGather, all_gather_rows, chunk_bounds, evaluate_sharded, max_shard, shard_bounds  # noqa: E402
 
 
 def test_shard_bounds_tile_the_batch():
@@ -76,3 +76,56 @@ def test_sharded_forward_uq_matches_single_process(tmp_path, world, n_total):
         got = np.load(tmp_path / f'rank{r}.npz')
         for k in ('V_cc', 'div_angle', 'T_c'):
             assert np.array_equal(got[k], want[k], equal_nan=True), (r, k)
+
+
+def test_chunk_bounds_tile_a_shard_on_tile_boundaries():
+    for n in (1, 63, 64, 65, 1000, 131072, 1_250_000):
+        for k in (1, 3, 4, 8, 10 ** 6):
+            b = chunk_bounds(n, k)
+            assert b[0][0] == 0 and sum(c for _, c in b) == n and all(first % 64 == 0 and c > 0 for first, c in b)
+            assert all(x[0] + x[1] == y[0] for x, y in zip(b, b[1:])) and len(b) <= max(1, k)
+            assert max(c for _, c in b) - min(c for _, c in b[:-1] or b) <= 64
+    assert chunk_bounds(0, 4) == []
+
+
+def _pipeline_worker(rank, world, port, n_local, chunks, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        pipe = ChunkedGather(n_local, 3, chunks, 'cpu')
+        state = {'step': 0}
+
+        def evaluate(first, count, out_rows):        # a stand-in model: row i of global sample g at step s
+            g = torch.arange(rank * n_local + first, rank * n_local + first + count, dtype=torch.float64)
+            for i in range(3):
+                out_rows[i, :count] = g * (i + 1) + 1000.0 * state['step']
+        for s in range(3):                           # repeated campaigns reuse the chunk buffers: the waits must hold
+            state['step'] = s
+            pipe.step(evaluate)
+        got = pipe.assemble()
+        g = torch.arange(world * n_local, dtype=torch.float64)
+        want = torch.stack([g * (i + 1) + 2000.0 for i in range(3)])
+        assert torch.equal(got, want), (rank, chunks)
+        assert len(pipe.bounds) == min(chunks, (n_local + 63) // 64)
+        Path(out_dir, f'ok{rank}').write_text('ok')
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,n_local,chunks', [(2, 1000, 1), (2, 1000, 4), (3, 777, 3), (2, 50, 8)])
+def test_chunked_gather_pipeline_restores_global_order(tmp_path, world, n_local, chunks):
+    """hallthrusterpem_amd.distributed.ChunkedGather: K chunk all-gathers issued while the next chunk is evaluated, over
+    repeated steps; every rank ends up with every rank's rows of the LAST step in global order."""
+    mp.spawn(_pipeline_worker, args=(world, _free_port(), n_local, chunks, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f'ok{r}').exists() for r in range(world))
+
+
+def test_chunked_gather_without_a_process_group_is_the_local_result():
+    pipe = ChunkedGather(300, 2, 3, 'cpu')
+
+    def evaluate(first, count, out_rows):
+        out_rows[0, :count] = torch.arange(first, first + count, dtype=torch.float64)
+        out_rows[1, :count] = -torch.arange(first, first + count, dtype=torch.float64)
+    pipe.step(evaluate)
+    got = pipe.assemble()
+    assert torch.equal(got[0], torch.arange(300, dtype=torch.float64)) and torch.equal(got[1], -got[0])
