@@ -576,6 +576,8 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
                     num = fma(w.y, f, num);
                     // norm(j_ion[k]) times basis row k, straight from the registers; past 90 degrees the basis rows are
                     // zero, but 0 * log10(0) is not
+                    // (the series log10, not the table one of pem_svd.hip: this loop is bound by its LDS reads of the basis, and a
+                    // per-lane table gather on top of them made it slower -- 457 against 393 us, profiles/svd_probe_r02c.txt)
                     double lj = io.log_norm ? pem::pem_log10(ji) : ji;
                     lj = in_range ? lj : 0.0;
                     const f64x2* brow = reinterpret_cast<const f64x2*>(m.basis + (k0 + j) * LAT_RT);

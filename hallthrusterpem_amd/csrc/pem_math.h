@@ -8,10 +8,55 @@
 // pem_exp10: n = rint(y*log2(10)), r = y - n*log10(2) [hi + lo], 10^r = exp(r ln10) by a degree-13 Taylor polynomial
 //   (|r ln10| <= ln2/2, truncation 1.3e-17), scaled by 2^n with ldexp; the argument is clamped to [-330, 310] where
 //   ldexp already gives 0 / inf.  Branch-free.
+//
+// pem_log10_tab: the same function from a 1024-entry table staged in LDS (tools/gen_log_table.py, csrc/pem_log_table.h):
+//   i = top 10 mantissa bits, r = fma(m, c_i, -1), log10 x = (e - [i < 424]) log10(2) + T_i + r P5(r).  No division, a
+//   degree-5 instead of a degree-7 polynomial, the special cases decided on the high dword with v_cmp_class: ~13 fp64 +
+//   ~12 fp32-rate instructions against ~40 fp64 ones (fp64 VALU issues at half the fp32 rate on this chip: measured 7.5
+//   cycles per wave instruction).  Largest error 1.3 ulp against a 64-bit-mantissa log10 (libm's own: 1.6 ulp).
 #pragma once
 #include <hip/hip_runtime.h>
 
+#ifndef PEM_TABLE_DECL
+#define PEM_TABLE_DECL static __device__ const
+#endif
+#include "pem_log_table.h"
+
 namespace pem {
+
+typedef double log_f64x2 __attribute__((ext_vector_type(2)));
+constexpr int LOG_TABLE_DOUBLES = 2 * PEM_LOG_N;
+
+// copy the table into LDS (called by every thread of the workgroup before a __syncthreads)
+__device__ __forceinline__ void load_log_table(double* lds_tab, int tid, int nthreads) {
+    for (int i = tid; i < LOG_TABLE_DOUBLES; i += nthreads) lds_tab[i] = PEM_LOG10_TAB[i];
+}
+
+__device__ __forceinline__ double pem_log10(double x);
+__device__ __forceinline__ double pem_log10_tab(double x, const double* lds_tab) {
+#ifdef PEM_LOG10_NO_TABLE                                     // A/B builds: the series version everywhere (tools/build_variant.sh)
+    return pem_log10(x);
+#endif
+    const double m = __builtin_amdgcn_frexp_mant(x);         // [1/2, 1); denormals normalised in hardware
+    int e = __builtin_amdgcn_frexp_exp(x);
+    const unsigned mh = (unsigned)__double2hiint(m);
+    const int i = (int)((mh >> (20 - PEM_LOG_NBITS)) & (PEM_LOG_N - 1));
+    e -= i < PEM_LOG_LOW_BELOW ? 1 : 0;
+    const log_f64x2 ct = reinterpret_cast<const log_f64x2*>(lds_tab)[i];       // one ds_read_b128
+    const double r = fma(m, ct.x, -1.0);
+    double p = PEM_LOG_A6;
+    p = fma(p, r, PEM_LOG_A5);
+    p = fma(p, r, PEM_LOG_A4);
+    p = fma(p, r, PEM_LOG_A3);
+    p = fma(p, r, PEM_LOG_A2);
+    p = fma(p, r, PEM_LOG_A1);
+    const double de = (double)e;
+    const double res = fma(de, 3.01029995663611771306e-01, ct.y) + fma(de, 3.69423907715893078616e-13, p * r);
+    // +-0 -> -inf, +inf -> +inf, negative and NaN -> NaN: the three constants differ in their high dword only
+    const bool ok = __builtin_amdgcn_class(x, 0x180);        // +subnormal | +normal
+    const unsigned sp = __builtin_amdgcn_class(x, 0x060) ? 0xfff00000u : (__builtin_amdgcn_class(x, 0x200) ? 0x7ff00000u : 0x7ff80000u);
+    return __hiloint2double(ok ? __double2hiint(res) : (int)sp, ok ? __double2loint(res) : 0);
+}
 
 __device__ __forceinline__ double pem_log10(double x) {
     // v_frexp_{mant,exp}_f64 normalise denormals in hardware: m in [1/2, 1)

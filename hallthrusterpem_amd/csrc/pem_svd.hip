@@ -39,9 +39,10 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 // MODE is a template parameter: as a run-time value hipcc evaluates log10()/exp10() for every element and selects
 // afterwards (the "none" mode then ran no faster than it would with the transcendental in it).
+// `logtab`: the LDS copy of the log10 table (pem_math.h), only read in the log10 mode
 template <int MODE>
-__device__ __forceinline__ double norm_fwd(double scale, double x) {
-    if constexpr (MODE == PEM_NORM_LOG10) return pem::pem_log10(x);
+__device__ __forceinline__ double norm_fwd(double scale, double x, const double* logtab) {
+    if constexpr (MODE == PEM_NORM_LOG10) return pem::pem_log10_tab(x, logtab);
     else if constexpr (MODE == PEM_NORM_LINEAR) return x * scale;
     else return x;
 }
@@ -61,7 +62,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 // registers and the occupancy stay what they are for the 91-point profile: with 16 x 202 values the kernel needed ~400
 // registers and 26 KB of LDS per wave, one wave per SIMD, and ran at 1.8 TB/s); lane = (row, k-group), KG = 64 / ROWS
 // interleaved k-slices.
-// LDS: basis_p[ksteps*KG][16] (zero padded) | per wave: tile[ROWS*dof] + KG zeroed slack doubles
+// LDS: basis_p[ksteps*KG][16] (zero padded) | per wave: tile[ROWS*dof] + KG zeroed slack doubles | log10 mode: table[2048]
 // UN = 16-byte pieces per lane of one tile (ceil(ROWS*dof/2/64)); the pieces of the NEXT tile are loaded into
 // registers while the current tile is multiplied.  RT = latent columns computed (>= rank, zero-padded basis).
 // Index arithmetic is kept 32-bit and out of the inner loops: the first version spent 1740 VALU instructions per
@@ -79,6 +80,8 @@ __global__ __launch_bounds__(BLOCK) void svd_compress_kernel(long long n, int do
     const int tile_doubles = (ROWS * dof + KG + 1) & ~1;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     double* tile = lds + ksteps * KG * 16 + wave * tile_doubles;  // [ROWS][dof] + slack
+    double* logtab = lds + ksteps * KG * 16 + WAVES * tile_doubles;  // log10 mode: 16 KB table behind the tiles
+    if constexpr (MODE == PEM_NORM_LOG10) pem::load_log_table(logtab, tid, BLOCK);
     for (int i = tid; i < ksteps * KG * 16; i += BLOCK) {
         const int k = i >> 4, c = i & 15;
         basis_p[i] = (k < dof && c < r) ? basis[(size_t)k * r + c] : 0.0;
@@ -127,8 +130,8 @@ __global__ __launch_bounds__(BLOCK) void svd_compress_kernel(long long n, int do
             const int i = 2 * (u * 64 + lane);
             if (i < tile_len) {
                 f64x2 w;
-                w.x = i < len ? norm_fwd<MODE>(scale, nxt[u].x) : 0.0;
-                w.y = i + 1 < len ? norm_fwd<MODE>(scale, nxt[u].y) : 0.0;
+                w.x = i < len ? norm_fwd<MODE>(scale, nxt[u].x, logtab) : 0.0;
+                w.y = i + 1 < len ? norm_fwd<MODE>(scale, nxt[u].y, logtab) : 0.0;
                 *reinterpret_cast<f64x2*>(tile + i) = w;
             }
         }
@@ -278,7 +281,8 @@ int pem_svd_compress_f64_dev(size_t n, int dof, int rank, int norm, double norm_
     // ROWS samples per tile: 16 (4 k-groups) for dof <= 96, 8 (8 k-groups) above; UN: 16-byte pieces per lane of a tile
     // (12 covers 16 x 96, 13 covers 8 x 208); RT: latent columns computed (>= rank)
     const int rows = dof <= 96 ? 16 : 8, kg = 64 / rows;
-    const size_t lds = ((size_t)((dof + kg - 1) / kg) * kg * 16 + (size_t)WAVES * ((rows * dof + kg + 1) & ~1)) * 8;
+    const size_t lds = ((size_t)((dof + kg - 1) / kg) * kg * 16 + (size_t)WAVES * ((rows * dof + kg + 1) & ~1) +
+                        (norm == PEM_NORM_LOG10 ? (size_t)pem::LOG_TABLE_DOUBLES : 0)) * 8;
     const size_t tiles = (n + rows - 1) / rows;
     size_t blocks = (tiles + WAVES - 1) / WAVES;
     if (blocks > 256 * 2) blocks = 256 * 2;

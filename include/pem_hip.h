@@ -260,6 +260,28 @@ int pem_coupled_mc_f64_dev(size_t n, uint64_t first_index, uint64_t seed, uint32
                            double* V_cc, double* I_B0, double* T, double* j_ion, double* div_angle, double* T_c,
                            uint8_t* invalid, pem_stream_t stream);
 
+/* ---- single-precision arithmetic: reduced QoIs and the fused Saltelli design (csrc/pem_fp32.hip) ----------------------
+ * SURVEY.md section 8b "fp32/mixed entry points optional with a tolerance report", section 8d config 5 (BASELINE
+ * configs[4]: Sobol' sensitivity, "fp64 -> fp32 mixed with tolerance check").  The same formulas as pem_coupled_f64_dev
+ * (cathode.py:24-38, tests/sim_hallthruster.jl:35-48, plume.py:39-140) evaluated in fp32 from fp32 tables; only the
+ * scalar QoIs are produced.  The tolerance report (fp32 against fp64 on identical inputs, per QoI) is
+ * hallthrusterpem_amd.fp32.compare_with_fp64 / bench.py --fp32 / tests/test_fp32.py.
+ *   x:   [15][ld] floats, rows in the order P_b V_a T_e V_vac Pstar P_T mdot_a a_1 c0..c5 sigma_cex
+ *   qoi: [3][ldq] floats: V_cc, div_angle, T_c;  invalid (optional): plume.py:105's flag per sample.                       */
+int pem_coupled_f32_dev(size_t n, float torr2pa, float radius, const float* x, size_t ld, float* qoi, size_t ldq,
+                        uint8_t* invalid, pem_stream_t stream);
+/* The Saltelli design of scripts/pem_v0/sobol.py:46-118 (uqtils sobol_sa, third-party: parity UNPINNED) as ONE launch:
+ * for base samples first_index .. first_index+n_base-1 the rows A (stream_id) and B (stream_id + 1) of the counter-based
+ * design -- the same numbers as pem_sample_f64_dev, rounded to float -- are generated in registers, the fp32 model is
+ * evaluated on A, B and on A with column varied[j] from B for j < n_varied, and the estimator sums are accumulated in
+ * fp64: partial[n_blocks][2 + 2 n_varied][3] (rows: sum fA+fB, sum fA^2+fB^2, then per varied input sum fB (fAB-fA) and
+ * sum (fA-fAB)^2; columns V_cc, div_angle, T_c), one deterministic partial per workgroup.  flags[n_blocks][2]: counts of
+ * non-physical thruster results (thruster.py:490-493: T < 0 or I_B0 < 0) and of invalid plume samples over all
+ * n_base (n_varied + 2) evaluations.  Nothing but the partial sums touches HBM.                                         */
+int pem_saltelli_f32_dev(size_t n_base, uint64_t first_index, uint64_t seed, uint32_t stream_id, const int32_t* kind,
+                         const double* a, const double* b, int n_varied, const int32_t* varied, float torr2pa,
+                         float radius, double* partial, uint64_t* flags, int n_blocks, pem_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

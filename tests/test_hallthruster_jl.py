@@ -145,7 +145,8 @@ def test_default_backend_one_run_at_a_time(g, tmp_path):
     out = _run(g['cases'][0], tmp_path)
     for key in ('T', 'I_B0', 'I_d', 'u_ion', 'u_ion_coords'):            # tests/test_thruster.py:95-96
         assert key in out
-    assert isinstance(out['T'], float) and isinstance(out['u_ion'], list) and len(out['u_ion']) == 100
+    # (200 cells, not the 100 of `simulation`: model_fidelity = (2, 2) overrides num_cells, thruster.py:159,253-255)
+    assert isinstance(out['T'], float) and isinstance(out['u_ion'], list) and len(out['u_ion']) == 200 == len(out['u_ion_coords'])
     json.dumps(out['thruster_output'])                                    # what the reference got from json.load is serialisable
 
 
