@@ -73,6 +73,7 @@ __device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x)
 
 // D(a), u = 1/a^2 (see pem_kernels.hip::normaliser): table for |a| >= 0.25, series below, NaN where the reference is NaN
 __device__ __forceinline__ float normaliser32(float a, float u, const float* dpoly) {
+#pragma clang fp contract(off)
     int i = (int)(2.0f * u);
     i = i < 0 ? 0 : (i > PEM32_NDI - 1 ? PEM32_NDI - 1 : i);
     const float x = fmaf(4.0f, u, -(float)(2 * i + 1));
@@ -96,6 +97,7 @@ __device__ __forceinline__ float normaliser32(float a, float u, const float* dpo
 
 // {Qd(a), Qn(a)}: the two divergence integrals of one beam (pem_kernels.hip::simpson_functionals), |a| >= QA_MIN
 __device__ __forceinline__ f32x2 functionals32(const f32x2* qpoly, float aa, float u) {
+#pragma clang fp contract(off)
     const bool wide = aa >= 0.25f;
     const float t = wide ? 2.0f * u : (aa - PEM32_QA_MIN) * PEM32_QB_SCALE;
     const int last = wide ? PEM32_NDI - 1 : PEM32_NQB - 1;
@@ -120,8 +122,11 @@ struct Qoi32 {
     bool invalid;
 };
 
-// One sample.  x: the 15 coupled inputs in the order of COUPLED_INPUTS.
+// One sample.  x: the 15 coupled inputs in the order of COUPLED_INPUTS.  Every fused multiply-add is written out and
+// the compiler is kept from forming others: the explicit-input kernel and the fused Saltelli kernel then evaluate the
+// same operations and give the same bits (tests/test_fp32.py holds the fused launch to the block-by-block pipeline).
 __device__ __forceinline__ Qoi32 coupled_f32(const float (&x)[NIN], float k, float rad, float inv_r2, float inv_2pi_r2, const Tab32& t) {
+#pragma clang fp contract(off)
     const float P_b = x[0], V_a = x[1], T_e = x[2], V_vac = x[3], Pstar = x[4], P_T = x[5], mdot = x[6], a_1 = x[7];
     const float c0 = x[8], c1 = x[9], c2 = x[10], c3 = x[11], c4 = x[12], c5 = x[13], sigma = x[14];
     Qoi32 o;
@@ -163,7 +168,7 @@ __device__ __forceinline__ Qoi32 coupled_f32(const float (&x)[NIN], float k, flo
         for (int kk = 0; kk < NANG; ++kk) {
             const float alpha = kk == NANG - 1 ? F_HALF_PI : (float)kk * F_GRID_H;
             const float t1 = alpha * frcp(a1), t2 = alpha * frcp(a2);
-            const float f = X1 * __expf(-(t1 * t1)) + X2 * __expf(-(t2 * t2));
+            const float f = fmaf(X1, __expf(-(t1 * t1)), X2 * __expf(-(t2 * t2)));
             lo = fminf(lo, f + j_cex);
             const f32x2 w = t.simpson[kk];
             d = fmaf(w.x, f, d);

@@ -1066,6 +1066,167 @@ __global__ __launch_bounds__(BLOCK) void plume_radii_kernel(PlumeIO io, RadiiArg
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// sweep_radius arrays with FEW radii, 2 <= R <= RADII_SMALL: the shape of tests/test_plume.py:31-style calls with a
+// handful of probe radii.  plume_radii_kernel above spends most of its instructions per SAMPLE on work that only R of
+// the 64 lanes take part in (the per-radius amplitudes and the divergence angle, lane = radius) -- 1.2-2.0 TB/s of output
+// for R = 2..5.  Here that work is done for a whole tile at once:
+//   prelude    lane = sample: the sample's parameters, then a loop over the R radii: decay, j_cex and the two beam
+//              amplitudes of every (sample, radius) pair go to LDS
+//   per sample the wave computes the two Gaussians (lane = angle; exp_nonpos instead of the library exp), their four
+//              Simpson functionals (one transposing wave reduction) and streams the (91, R) block, 16 bytes per lane
+//   postlude   lane = (sample, radius) pair: cos_div, arccos, T_c for the whole tile, coalesced stores
+// Samples whose amplitudes are of opposite sign or near the overflow threshold take the literal angle-by-angle sums for
+// the divergence integrals, exactly as in plume_radii_kernel (rare).
+// ---------------------------------------------------------------------------------------------
+constexpr int RADII_SMALL = 8;
+constexpr int RS_TS = 64;            // samples per wave tile
+struct RadiiSmallArg {
+    double r[RADII_SMALL];
+};
+
+// sum four per-lane values over the wave; lane l ends up with the total of v[2 (l & 1) + ((l >> 1) & 1)]
+__device__ __forceinline__ double wave_sum4(const double (&v)[4], int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2;
+    double w2[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const double send = b0 ? v[k] : v[k + 2], keep = b0 ? v[k + 2] : v[k];
+        w2[k] = keep + __shfl_xor(send, 1);
+    }
+    const double send = b1 ? w2[0] : w2[1], keep = b1 ? w2[1] : w2[0];
+    double w = keep + __shfl_xor(send, 2);
+#pragma unroll
+    for (int m = 4; m < WAVE; m <<= 1) w += __shfl_xor(w, m);
+    return w;
+}
+
+__global__ __launch_bounds__(BLOCK) void plume_radii_small_kernel(PlumeIO io, RadiiSmallArg radii_arg, int R, int ts) {
+#pragma clang fp contract(off)
+    // per wave: e1[96] e2[96] | S[RS_TS][4] | PB[RS_TS * R][3] {b1, b2, j_cex}
+    __shared__ double lds_all[BLOCK / WAVE][2 * 96 + RS_TS * 4 + RS_TS * RADII_SMALL * 3];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double* e1 = lds_all[wave];
+    double* e2 = e1 + 96;
+    double* S = e2 + 96;
+    double* PB = S + RS_TS * 4;
+    const long long nwaves = (long long)gridDim.x * (BLOCK / WAVE);
+    const bool have_T = io.T != nullptr;
+    const long long ntiles = (io.n + ts - 1) / ts;
+    const int slot4 = 2 * (lane & 1) + ((lane >> 1) & 1);
+    const int blk = NANG * R;                              // doubles per sample block
+    for (long long t = blockIdx.x * (BLOCK / WAVE) + wave; t < ntiles; t += nwaves) {
+        const int in_tile = (int)(io.n - t * ts < ts ? io.n - t * ts : ts);
+        const long long gl = lane < in_tile ? t * ts + lane : io.n - 1;    // idle lanes repeat the last sample
+        const double c0_l = io.c0[gl], c1_l = io.c1[gl];
+        const PlumeSetup ps_l = plume_setup(io.P_b[gl], c1_l, io.c2[gl], io.c3[gl], io.c4[gl], io.c5[gl], io.torr2pa);
+        const double a1_l = ps_l.a1, a2_l = ps_l.a2, sigma_l = io.sigma[gl], IB0_l = io.I_B0[gl];
+        const double A1_l = (1.0 - c0_l) / normaliser(a1_l, 1.0 / (a1_l * a1_l), PEM_DPOLY);
+        const double A2_l = c0_l / normaliser(a2_l, 1.0 / (a2_l * a2_l), PEM_DPOLY);
+        unsigned literal_l = 0;                             // bit r: (sample, radius r) sums its integrals angle by angle
+        for (int r = 0; r < R; ++r) {
+            const double rad = radii_arg.r[r];
+            const double decay = exp(-rad * ps_l.n_neutral * sigma_l);
+            const double j_cex = IB0_l * (1.0 - decay) / (2.0 * PEM_PI * (rad * rad));
+            const double base = IB0_l * decay / (rad * rad);
+            const double b1 = base * A1_l, b2 = base * A2_l;
+            double* pb = PB + (lane * R + r) * 3;
+            pb[0] = b1;
+            pb[1] = b2;
+            pb[2] = j_cex;
+            if (!(fabs(b1) + fabs(b2) < 1e300) || ((b1 < 0.0) != (b2 < 0.0) && b1 != 0.0 && b2 != 0.0)) literal_l |= 1u << r;
+        }
+        wave_lds_sync();
+        for (int smp = 0; smp < in_tile; ++smp) {
+            const long long g = t * ts + smp;
+            const double a1 = __shfl(a1_l, smp), a2 = __shfl(a2_l, smp);
+            const unsigned literal = (unsigned)__shfl((int)literal_l, smp);
+            // the two Gaussians of plume.py:99-100 and their four Simpson functionals
+            double part[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int k = lane; k < NANG; k += WAVE) {
+                const double alpha = k == NANG - 1 ? HALF_PI : (double)k * GRID_H;
+                const double t1 = alpha / a1, t2 = alpha / a2;
+                const double g1 = exp_nonpos(-(t1 * t1)), g2 = exp_nonpos(-(t2 * t2));
+                e1[k] = g1;
+                e2[k] = g2;
+                part[0] = __builtin_fma(PEM_SIMPSON_CDEN[k], g1, part[0]);
+                part[1] = __builtin_fma(PEM_SIMPSON_CNUM[k], g1, part[1]);
+                part[2] = __builtin_fma(PEM_SIMPSON_CDEN[k], g2, part[2]);
+                part[3] = __builtin_fma(PEM_SIMPSON_CNUM[k], g2, part[3]);
+            }
+            const double tot = wave_sum4(part, lane);
+            if (lane < 4) S[smp * 4 + slot4] = tot;        // S[smp] = {s1d, s1n, s2d, s2n}
+            wave_lds_sync();
+            if (literal) {   // rare, wave-uniform: the reference's own summation order for the flagged radii
+                if (lane < R && ((literal >> lane) & 1)) {
+                    const double* pb = PB + (smp * R + lane) * 3;
+                    double den = 0.0, num = 0.0;
+                    for (int k = 0; k < NANG; ++k) {
+                        const double f = pb[0] * e1[k] + pb[1] * e2[k];
+                        den = __builtin_fma(PEM_SIMPSON_CDEN[k], f, den);
+                        num = __builtin_fma(PEM_SIMPSON_CNUM[k], f, num);
+                    }
+                    double cos_div = num / den;
+                    if (cos_div == __builtin_inf()) cos_div = __builtin_nan("");
+                    io.div[(size_t)g * R + lane] = acos(cos_div);
+                    if (have_T) io.Tc[(size_t)g * R + lane] = io.T[g] * cos_div;
+                }
+            }
+            // the (91, R) block, contiguous: element idx = k R + r.  Lanes take PAIRS of elements (16-byte stores); a block
+            // that starts at an odd double (91 R odd and g odd) is shifted by one element, which lane 0 stores on its own.
+            double* dst = io.j_ion + (size_t)g * blk;
+            const double* pbs = PB + smp * R * 3;
+            const int odd = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
+            bool bad = a1 <= 0.0;
+            auto value = [&](int idx) {
+                const int k = idx / R, r = idx - k * R;
+                const double* pb = pbs + r * 3;
+                return (pb[0] * e1[k] + pb[1] * e2[k]) + pb[2];
+            };
+            if (odd && lane == 0) {
+                const double ji = value(0);
+                bad |= ji <= 0.0;
+                dst[0] = ji;
+            }
+            for (int idx = odd + 2 * lane; idx < blk; idx += 2 * WAVE) {
+                const double j0 = value(idx);
+                bad |= j0 <= 0.0;
+                if (idx + 1 < blk) {
+                    const double j1 = value(idx + 1);
+                    bad |= j1 <= 0.0;
+                    f64x2 v;
+                    v.x = j0;
+                    v.y = j1;
+                    __builtin_nontemporal_store(v, reinterpret_cast<f64x2*>(dst + idx));
+                } else {
+                    dst[idx] = j0;
+                }
+            }
+            const bool invalid = __ballot(bad) != 0;
+            if (invalid)   // plume.py:106: the whole block becomes 1e-20 (rare: a second pass over it)
+                for (int idx = lane; idx < blk; idx += WAVE) dst[idx] = 1e-20;
+            if (io.invalid && lane == 0) io.invalid[g] = (uint8_t)invalid;
+            wave_lds_sync();   // e1 / e2 are rewritten for the next sample
+        }
+        // postlude: the divergence angle of every (sample, radius) pair of the tile (linear in the amplitudes)
+        const int pairs = in_tile * R;
+        for (int idx = lane; idx < pairs; idx += WAVE) {
+            const int smp = idx / R, r = idx - smp * R;
+            const unsigned literal = (unsigned)__shfl((int)literal_l, smp);
+            if ((literal >> r) & 1) continue;
+            const double* pb = PB + idx * 3;
+            const double* sv = S + smp * 4;
+            const double num = pb[0] * sv[1] + pb[1] * sv[3], den = pb[0] * sv[0] + pb[1] * sv[2];
+            double cos_div = num / den;
+            if (cos_div == __builtin_inf()) cos_div = __builtin_nan("");
+            const long long g = t * ts + smp;
+            io.div[(size_t)g * R + r] = acos(cos_div);
+            if (have_T) io.Tc[(size_t)g * R + r] = io.T[g] * cos_div;
+        }
+        wave_lds_sync();   // PB / S are rewritten by the next tile
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void cathode_kernel(long long n, const double* __restrict__ P_b,
                                                         const double* __restrict__ V_a, const double* __restrict__ T_e,
                                                         const double* __restrict__ V_vac,
@@ -1472,6 +1633,19 @@ int pem_plume_f64_dev(size_t n, int n_radii, const double* radii, double torr2pa
     PlumeIO io{(long long)n, torr2pa, radii[0], P_b, c0, c1, c2, c3, c4, c5, sigma_cex, I_B0, T, j_ion, div_angle, T_c, invalid};
     if (n_radii == 1 && aligned16(j_ion)) return dispatch_lanes<false, 1>(io, CoupledIO{}, st);
 
+    if (n_radii >= 2 && n_radii <= RADII_SMALL && !getenv("PEM_RADII_GENERAL")) {
+        // few radii: the per-radius work of a whole tile at once (R = 2..5: 1.2-2.0 -> ~3 TB/s of output, tools/radii_probe.py)
+        RadiiSmallArg ra;
+        for (int r = 0; r < RADII_SMALL; ++r) ra.r[r] = r < n_radii ? radii[r] : 1.0;
+        int ts = RS_TS;
+        while (ts > 4 && (n + ts - 1) / ts < 256 * 16) ts >>= 1;
+        const size_t ntiles = (n + ts - 1) / ts;
+        size_t blocks = (ntiles + BLOCK / WAVE - 1) / (BLOCK / WAVE);
+        if (blocks > 256 * 2) blocks = 256 * 2;   // persistent: 63 KB of LDS per workgroup, two per CU
+        hipLaunchKernelGGL(plume_radii_small_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, st, io, ra, n_radii, ts);
+        HIP_TRY(hipGetLastError());
+        return PEM_OK;
+    }
     if (n_radii >= 2 && n_radii <= RADII_MAX) {
         // wave per sample, coalesced (91, R) blocks, literal Gaussians (per 1e5..1e6 samples, tools/radii_probe.py: R = 25:
         // 7415 -> 614 us, R = 5: 2089 -> 795 us, R = 3: 1262 -> 940 us, R = 2: 1183 -> 1314 us)

@@ -67,7 +67,13 @@ __device__ __forceinline__ void wave_lds_sync() {
 // registers while the current tile is multiplied.  RT = latent columns computed (>= rank, zero-padded basis).
 // Index arithmetic is kept 32-bit and out of the inner loops: the first version spent 1740 VALU instructions per
 // 16-sample tile, most of them 64-bit address math (rocprofv3 SQ_INSTS_VALU), and ran at 2.3 TB/s.
-template <int ROWS, int UN, int RT, int MODE>
+// MFMA = true (ROWS = 16 only): the tile's 16 x dof by dof x 16 product on v_mfma_f64_16x16x4_f64 instead of VALU FMAs.
+// Measured rates (profiles/microbench_rates_r02c.txt): the fp64 matrix pipe sustains 78 TFLOP/s from one wave per SIMD
+// and runs beside the VALU; v_fma_f64 reaches 39-60.  Without a norm the kernel is HBM-bound and the VALU form (no padding
+// of the rank to 16 columns, no dependent MFMA chain) is as fast; with the log10 norm the VALU is what the kernel waits
+// for (profiles/compress_pmc_r02d.txt: 55 VALU instructions per value, VALU active 2/3 of the time at two waves per
+// SIMD), and moving the 8 FMAs + 4 basis reads per value to the matrix pipe takes a quarter of them away.
+template <int ROWS, int UN, int RT, int MODE, bool MFMA = false>
 __global__ __launch_bounds__(BLOCK) void svd_compress_kernel(long long n, int dof, int r, double scale,
                                                              const double* __restrict__ field,
                                                              const double* __restrict__ basis,
@@ -140,45 +146,74 @@ __global__ __launch_bounds__(BLOCK) void svd_compress_kernel(long long n, int do
         if (t + 2 * stride < ntiles) fetch(field + (t + 2 * stride) * tile_len, tile_length(t + 2 * stride), nxt2);
         wave_lds_sync();
 
-        // lane (row = sample, quad): partial dot products over k = quad, quad + 4, ... for RT latent columns
-        double acc[RT];
+        if constexpr (MFMA) {
+            static_assert(!MFMA || ROWS == 16, "the 16x16x4 tile is 16 samples by 16 latent columns");
+            // D[16 samples][16 columns] += A[16][4] B[4][16] per k-step: lane (row, quad) feeds A[row][4 step + quad] =
+            // tile[row][k] and B[4 step + quad][row] = basis_p[k][column = row]; two accumulators halve the dependent chain
+            f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+            const double* ap = a_base;
+            const double* bp = basis_p + quad * 16 + row;
+            int step = 0;
+            for (; step + 2 < ksteps; step += 2) {
+                const double a0 = ap[0], a1 = ap[KG], b0 = bp[0], b1 = bp[KG * 16];
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
+                ap += 2 * KG;
+                bp += 2 * KG * 16;
+            }
+            for (; step < ksteps; ++step) {   // the last one or two steps: k >= dof is masked (0 * inf = NaN otherwise)
+                const double a = quad + KG * step < dof ? *ap : 0.0;
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, *bp, acc0, 0, 0, 0);
+                ap += KG;
+                bp += KG * 16;
+            }
+            // lane (row, quad) holds D[quad + 4 i][column = row], i = 0..3
+            wave_lds_sync();
+            if (row < r) {
 #pragma unroll
-        for (int j = 0; j < RT; ++j) acc[j] = 0.0;
-        const double* ap = a_base;
-        const f64x2* bp = b_base;
+                for (int i = 0; i < 4; ++i) tile[(quad + 4 * i) * r + row] = acc0[i] + acc1[i];
+            }
+        } else {
+            // lane (row = sample, quad): partial dot products over k = quad, quad + 4, ... for RT latent columns
+            double acc[RT];
+#pragma unroll
+            for (int j = 0; j < RT; ++j) acc[j] = 0.0;
+            const double* ap = a_base;
+            const f64x2* bp = b_base;
 #pragma unroll 4
-        for (int step = 0; step < ksteps - 1; ++step) {
-            const double a = *ap;
-            ap += KG;
+            for (int step = 0; step < ksteps - 1; ++step) {
+                const double a = *ap;
+                ap += KG;
 #pragma unroll
-            for (int j = 0; j < RT; j += 2) {
-                const f64x2 b = bp[j >> 1];
-                acc[j] = fma(a, b.x, acc[j]);
-                if (j + 1 < RT) acc[j + 1] = fma(a, b.y, acc[j + 1]);
+                for (int j = 0; j < RT; j += 2) {
+                    const f64x2 b = bp[j >> 1];
+                    acc[j] = fma(a, b.x, acc[j]);
+                    if (j + 1 < RT) acc[j + 1] = fma(a, b.y, acc[j + 1]);
+                }
+                bp += KG * 8;                     // KG basis rows of 16 doubles
             }
-            bp += KG * 8;                     // KG basis rows of 16 doubles
-        }
-        {   // last step: k >= dof would read the next sample's first values (or slack) against a zero basis row --
-            // masked, because 0 * inf = NaN would let one sample's non-finite value poison its neighbour's latents
-            const double a = quad + KG * (ksteps - 1) < dof ? *ap : 0.0;
+            {   // last step: k >= dof would read the next sample's first values (or slack) against a zero basis row --
+                // masked, because 0 * inf = NaN would let one sample's non-finite value poison its neighbour's latents
+                const double a = quad + KG * (ksteps - 1) < dof ? *ap : 0.0;
 #pragma unroll
-            for (int j = 0; j < RT; j += 2) {
-                const f64x2 b = bp[j >> 1];
-                acc[j] = fma(a, b.x, acc[j]);
-                if (j + 1 < RT) acc[j + 1] = fma(a, b.y, acc[j + 1]);
+                for (int j = 0; j < RT; j += 2) {
+                    const f64x2 b = bp[j >> 1];
+                    acc[j] = fma(a, b.x, acc[j]);
+                    if (j + 1 < RT) acc[j + 1] = fma(a, b.y, acc[j + 1]);
+                }
             }
+#pragma unroll
+            for (int j = 0; j < RT; ++j) {
+#pragma unroll
+                for (int sh = ROWS; sh < 64; sh <<= 1) acc[j] += __shfl_xor(acc[j], sh);
+            }
+            // every k-group now holds the full sums.  The tile's ROWS x r latents are one contiguous block of `latent`:
+            // gather them in LDS (the tile is consumed) and store them with consecutive lanes.
+            wave_lds_sync();
+#pragma unroll
+            for (int j = 0; j < RT; ++j)
+                if ((j & (KG - 1)) == quad && j < r) tile[row * r + j] = acc[j];
         }
-#pragma unroll
-        for (int j = 0; j < RT; ++j) {
-#pragma unroll
-            for (int sh = ROWS; sh < 64; sh <<= 1) acc[j] += __shfl_xor(acc[j], sh);
-        }
-        // every k-group now holds the full sums.  The tile's ROWS x r latents are one contiguous block of `latent`:
-        // gather them in LDS (the tile is consumed) and store them with consecutive lanes.
-        wave_lds_sync();
-#pragma unroll
-        for (int j = 0; j < RT; ++j)
-            if ((j & (KG - 1)) == quad && j < r) tile[row * r + j] = acc[j];
         wave_lds_sync();
         {
             double* out = latent + t * ROWS * r;
@@ -294,9 +329,18 @@ int pem_svd_compress_f64_dev(size_t n, int dof, int rank, int norm, double norm_
         hipLaunchKernelGGL((svd_compress_kernel<ROWS_, UN_, RT_, MODE_>), dim3((unsigned)blocks), dim3(BLOCK), lds, \
                            static_cast<hipStream_t>(stream), (long long)n, dof, rank, norm_scale, field, basis, latent); \
     } while (0)
+#define PEM_SVD_LAUNCH_MFMA()                                                                                          \
+    do {                                                                                                             \
+        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(svd_compress_kernel<16, 12, 16, PEM_NORM_LOG10, true>), \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);        \
+        HIP_TRY(attr);                                                                                               \
+        hipLaunchKernelGGL((svd_compress_kernel<16, 12, 16, PEM_NORM_LOG10, true>), dim3((unsigned)blocks), dim3(BLOCK), lds, \
+                           static_cast<hipStream_t>(stream), (long long)n, dof, rank, norm_scale, field, basis, latent); \
+    } while (0)
 #define PEM_SVD_BY_MODE(ROWS_, UN_, RT_)                                                 \
     do {                                                                            \
-        if (norm == PEM_NORM_LOG10) PEM_SVD_LAUNCH(ROWS_, UN_, RT_, PEM_NORM_LOG10);       \
+        if (norm == PEM_NORM_LOG10 && ROWS_ == 16 && !getenv("PEM_SVD_NO_MFMA")) PEM_SVD_LAUNCH_MFMA();       \
+        else if (norm == PEM_NORM_LOG10) PEM_SVD_LAUNCH(ROWS_, UN_, RT_, PEM_NORM_LOG10);       \
         else if (norm == PEM_NORM_LINEAR) PEM_SVD_LAUNCH(ROWS_, UN_, RT_, PEM_NORM_LINEAR); \
         else PEM_SVD_LAUNCH(ROWS_, UN_, RT_, PEM_NORM_NONE);                                \
     } while (0)
@@ -307,6 +351,7 @@ int pem_svd_compress_f64_dev(size_t n, int dof, int rank, int norm, double norm_
         if (rt == 4) PEM_SVD_BY_MODE(8, 13, 4); else if (rt == 8) PEM_SVD_BY_MODE(8, 13, 8); else PEM_SVD_BY_MODE(8, 13, 16);
     }
 #undef PEM_SVD_BY_MODE
+#undef PEM_SVD_LAUNCH_MFMA
 #undef PEM_SVD_LAUNCH
     HIP_TRY(hipGetLastError());
     return PEM_OK;

@@ -178,7 +178,7 @@ def generate_data_on_device(n: int, seed: int = 0, description: str = 'test_set'
 
 # ------------------------------------------------------------------------------------------- Sobol' indices
 def sobol_indices(n_base: int, seed: int = 0, qois=QOI_NAMES, priors=None, fixed: dict | None = None,
-                  batch_size: int = 1 << 20, device=None, group=None):
+                  batch_size: int = 1 << 20, device=None, group=None, precision: str = 'fp64'):
     """First-order and total Sobol' indices of scalar QoIs by the Saltelli design: N (d + 2) evaluations for the
     d non-constant inputs (matrices A, B and A with column i from B), `compute_s2=False` as sobol.py:113 asks.
 
@@ -186,7 +186,13 @@ def sobol_indices(n_base: int, seed: int = 0, qois=QOI_NAMES, priors=None, fixed
         S1_i = mean( f(B) * (f(AB_i) - f(A)) ) / Var          ST_i = mean( (f(A) - f(AB_i))^2 ) / (2 Var)
     `fixed` pins inputs (e.g. operating conditions at nominal, as sobol.py:104 does) -- they are not varied.
     With a torch.distributed `group` every rank evaluates its shard of the N base samples and the sums are
-    all-reduced (O(d * n_qoi) doubles).  Returns {'S1': {qoi: [d]}, 'ST': ..., 'inputs': names}."""
+    all-reduced (O(d * n_qoi) doubles).  Returns {'S1': {qoi: [d]}, 'ST': ..., 'inputs': names}.
+
+    precision='fp32' (BASELINE configs[4]: "fp64 -> fp32 mixed with tolerance check"): the SAME design -- the fp64
+    counter-based rows, rounded to float -- through the fp32-arithmetic model, the whole shard in ONE launch that keeps
+    design rows, QoIs and estimator terms in registers (`pem_saltelli_f32_dev`, csrc/pem_fp32.hip) and accumulates the
+    sums in fp64.  The result also carries `non_physical` / `invalid` counts (the thruster filter of thruster.py:490-493
+    and plume.py:105 over all evaluations).  fp32.compare_with_fp64 is the per-QoI tolerance report of the model."""
     import torch
     import torch.distributed as dist
     pri = dict(sampling.PEM_V0_PRIORS if priors is None else priors)
@@ -205,6 +211,18 @@ def sobol_indices(n_base: int, seed: int = 0, qois=QOI_NAMES, priors=None, fixed
     rows = [{'V_cc': 0, 'div_angle': 1, 'T_c': 2}.get(k) for k in qois]
     if any(r is None for r in rows):
         raise ValueError(f'sobol_indices handles the scalar QoIs V_cc, div_angle, T_c; got {qois}')
+    if precision not in ('fp64', 'fp32'):
+        raise ValueError("precision must be 'fp64' or 'fp32'")
+    counts = None
+    if precision == 'fp32':
+        from .fp32 import saltelli_sums
+        counts = torch.zeros(2, dtype=torch.int64, device=dev)
+        if hi > lo:
+            sums, counts = saltelli_sums(design, varied, hi - lo, first_index=lo, device=dev)
+            sums = sums[:, rows]
+            acc[0], acc[1], acc[2] = sums[0], sums[1], 2 * (hi - lo)
+            acc[3:3 + nd], acc[3 + nd:] = sums[2::2], sums[3::2]
+        lo = hi                                                        # nothing left for the block loop below
     import ctypes as C
     from . import _lib
     lib = _lib.load()
@@ -246,6 +264,8 @@ def sobol_indices(n_base: int, seed: int = 0, qois=QOI_NAMES, priors=None, fixed
         acc[3 + nd:] += s[1:, :, 1]
     if world > 1:
         dist.all_reduce(acc, group=group)
+        if counts is not None:
+            dist.all_reduce(counts, group=group)
     cnt = acc[2]
     mean = acc[0] / cnt
     var = acc[1] / cnt - mean * mean
@@ -253,9 +273,12 @@ def sobol_indices(n_base: int, seed: int = 0, qois=QOI_NAMES, priors=None, fixed
     S1 = acc[3:3 + nd] / n_tot / var
     ST = acc[3 + nd:] / n_tot / (2 * var)
     names = [design.names[d] for d in varied]
-    return {'S1': {q: S1[:, i] for i, q in enumerate(qois)}, 'ST': {q: ST[:, i] for i, q in enumerate(qois)},
-            'inputs': names, 'mean': {q: mean[i] for i, q in enumerate(qois)}, 'var': {q: var[i] for i, q in enumerate(qois)},
-            'evaluations': int(n_base) * (nd + 2)}
+    res = {'S1': {q: S1[:, i] for i, q in enumerate(qois)}, 'ST': {q: ST[:, i] for i, q in enumerate(qois)},
+           'inputs': names, 'mean': {q: mean[i] for i, q in enumerate(qois)}, 'var': {q: var[i] for i, q in enumerate(qois)},
+           'evaluations': int(n_base) * (nd + 2), 'precision': precision}
+    if counts is not None:
+        res['non_physical'], res['invalid'] = int(counts[0]), int(counts[1])
+    return res
 
 
 # ------------------------------------------------------------------------------------------- rejection of plume spikes

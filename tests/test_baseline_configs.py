@@ -144,7 +144,14 @@ def test_config_2e7_saltelli_design():
             # and the full design agrees with its own first 80 000 base samples to Monte-Carlo accuracy
             assert float(full['ST'][q][j]) == pytest.approx(st[i], abs=0.02)
 
-    # "fp64 -> fp32 mixed with tolerance check": the same fp64 arithmetic, profile stored as fp32, on identical inputs
+    # "fp64 -> fp32 ... with tolerance check", arithmetic: the same 2e7-evaluation design through the fp32 model in one
+    # fused launch (tests/test_fp32.py holds the model's per-QoI tolerance report and the launch's exactness)
+    f32 = drivers.sobol_indices(n_base, seed=1, fixed=fixed, precision='fp32')
+    assert f32['evaluations'] == full['evaluations'] and f32['non_physical'] == 0 and f32['invalid'] == 0
+    for q in ('V_cc', 'div_angle', 'T_c'):
+        assert float((f32['S1'][q] - full['S1'][q]).abs().max()) < 2e-4 and float((f32['ST'][q] - full['ST'][q]).abs().max()) < 2e-4
+
+    # ... and storage: the same fp64 arithmetic, profile stored as fp32, on identical inputs
     n = 2_000_000
     f64, mix = CoupledBatch(n), CoupledBatch(n, mixed=True)
     sampling.Design(seed=2).fill(f64.inputs)

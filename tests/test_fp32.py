@@ -1,0 +1,110 @@
+"""Single-precision arithmetic (csrc/pem_fp32.hip, hallthrusterpem_amd/fp32.py): SURVEY.md section 8b "fp32/mixed entry
+points optional with a tolerance report", section 8d config 5 "fp32 run compared with fp64 on identical inputs; report
+max / 99.9-pct relative error per QoI".  The tolerances asserted here ARE that report's bounds (with margin over what was
+measured on MI355X: see profiles/fp32_report_r02.json); the fused Saltelli launch is held to the block-by-block fp32
+pipeline exactly (same floats, fp64 sums) and to the fp64 driver on the same design."""
+import json
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fp32_model_against_fp64_on_identical_inputs():
+    from hallthrusterpem_amd.fp32 import compare_with_fp64
+    rep = compare_with_fp64(2_000_000, seed=2)
+    print(json.dumps(rep, indent=1))
+    assert rep['invalid_flags_identical']
+    q = rep['qoi']
+    # V_cc = V_vac + T_e ln(1 + PB/PT) - T_e PB / (PT + P*): a few fp32 roundings of O(10 V) terms; clipped at 0 where it cancels
+    assert q['V_cc']['p999_rel'] <= 2e-6 and q['V_cc']['median_rel'] <= 2e-7
+    # T_c = T cos_div: T one sqrt and two products, cos_div a ratio of two degree-6 table polynomials
+    assert q['T_c']['p999_rel'] <= 5e-6 and q['T_c']['max_rel'] <= 5e-5
+    # div_angle = arccos(cos_div): the error of cos_div divided by sin(angle) -- the widest tail of the three
+    assert q['div_angle']['p999_rel'] <= 2e-5 and q['div_angle']['max_rel'] <= 1e-3
+    assert all(v['compared'] >= 1_990_000 for v in q.values())
+
+
+def test_fp32_semantics_outside_the_plain_path():
+    """alpha1 <= 0 (invalid), c0 outside [0, 1] (a negative amplitude: the literal 91-term sums), narrow beams below the
+    table range, NaN propagation: same flags as the fp64 kernel, values to fp32 accuracy of the cancelling sums."""
+    import torch
+    from hallthrusterpem_amd.batch import CoupledBatch
+    from hallthrusterpem_amd.fp32 import CoupledBatchF32
+    from hallthrusterpem_amd.models.coupled import COUPLED_INPUTS
+    base = {'P_b': 1e-5, 'V_a': 300.0, 'T_e': 3.0, 'V_vac': 30.0, 'Pstar': 2e-5, 'P_T': 5e-5, 'mdot_a': 5e-6, 'a_1': 0.01,
+            'c0': 0.5, 'c1': 0.5, 'c2': -8.0, 'c3': 0.3, 'c4': 1e20, 'c5': 1e16, 'sigma_cex': 55e-20}
+    edits = [{}, {'c2': 0.0, 'c3': -0.3}, {'c0': 1.2}, {'c0': -0.1}, {'c2': 0.0, 'c3': 0.02}, {'c2': 0.0, 'c3': 0.1}, {'c3': float('nan')},
+             {'c2': 0.0, 'c3': 0.0}, {'mdot_a': -5e-6}, {'c2': 0.0, 'c3': 1.5, 'c1': 0.02}, {'V_vac': 0.0, 'T_e': 1.0}]
+    n = len(edits)
+    x = {k: np.array([{**base, **e}[k] for e in edits]) for k in COUPLED_INPUTS}
+    f32 = CoupledBatchF32(n)
+    for i, k in enumerate(COUPLED_INPUTS):
+        f32.inputs[i] = torch.from_numpy(x[k]).float().cuda()
+    f64 = CoupledBatch(n, profile=False)
+    f64.inputs.copy_(f32.inputs)
+    f32.run()
+    f64.run()
+    torch.cuda.synchronize()
+    assert torch.equal(f32.invalid, f64.invalid)
+    got, want = f32.qoi.double().cpu().numpy(), f64.qoi.cpu().numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    fin = np.isfinite(want)
+    assert np.max(np.abs(got[fin] - want[fin]) / np.maximum(np.abs(want[fin]), 1e-3)) < 2e-4
+    assert f32.invalid[1] == 1 and f32.invalid[7] == 1 and np.isnan(got[1, 6]) and np.isnan(got[1, 7])
+
+
+def test_fused_saltelli_launch_equals_the_block_by_block_fp32_pipeline():
+    import torch
+    from hallthrusterpem_amd import sampling
+    from hallthrusterpem_amd.fp32 import CoupledBatchF32, saltelli_sums
+    fixed = {'P_b': 1e-5, 'V_a': 300.0, 'mdot_a': 5e-6}
+    pri = dict(sampling.PEM_V0_PRIORS)
+    for k, v in fixed.items():
+        pri[k] = sampling.Prior(sampling.UNIFORM, v, v, 'fixed')
+    design = sampling.Design(priors=pri, seed=11)
+    varied = [i for i, k in enumerate(design.names) if k not in fixed]
+    for N, first in ((20_000, 0), (1000, 12345), (63, 7)):
+        sums, flags = saltelli_sums(design, varied, N, first_index=first)
+        x64 = torch.empty((15, N), dtype=torch.float64, device='cuda')
+        b = CoupledBatchF32(N)
+
+        def block(swap):
+            design.fill(x64, first_index=first, swap_dim=swap)
+            b.inputs.copy_(x64)
+            b.run()
+            torch.cuda.synchronize()
+            return b.qoi.double().cpu().numpy().T.copy()           # (N, 3)
+        fA, fB = block(-1), block(-2)
+        want = np.zeros((2 + 2 * len(varied), 3))
+        want[0], want[1] = (fA + fB).sum(0), (fA * fA + fB * fB).sum(0)
+        for j, d in enumerate(varied):
+            fAB = block(d)
+            want[2 + 2 * j], want[3 + 2 * j] = (fB * (fAB - fA)).sum(0), ((fA - fAB) ** 2).sum(0)
+        got = sums.cpu().numpy()
+        scale = np.maximum(np.abs(want), np.abs(want[1])[None, :] * 1e-6)      # rows that are exactly 0 (V_cc vs plume inputs)
+        assert np.max(np.abs(got - want) / scale) < 1e-11, (N, first)
+        assert flags.tolist() == [0, 0]
+    # the thruster filter inside the launch: a design with negative flow rates is counted, not dropped
+    pri['mdot_a'] = sampling.Prior(sampling.UNIFORM, -1e-6, 1e-6, 'test')
+    design = sampling.Design(priors=pri, seed=11)
+    _, flags = saltelli_sums(design, varied, 5000)
+    assert 0.4 * 5000 * 14 < int(flags[0]) < 0.6 * 5000 * 14
+
+
+def test_sobol_indices_fp32_against_fp64_on_the_same_design():
+    from hallthrusterpem_amd import drivers
+    fixed = {'P_b': 1e-5, 'V_a': 300.0, 'mdot_a': 5e-6}
+    N = 200_000
+    a = drivers.sobol_indices(N, seed=4, fixed=fixed, batch_size=1 << 18)
+    b = drivers.sobol_indices(N, seed=4, fixed=fixed, precision='fp32')
+    assert a['inputs'] == b['inputs'] and b['evaluations'] == N * 14 and b['non_physical'] == 0 and b['invalid'] == 0
+    worst = 0.0
+    for q in ('V_cc', 'div_angle', 'T_c'):
+        for key in ('S1', 'ST'):
+            worst = max(worst, float((a[key][q] - b[key][q]).abs().max()))
+        assert float(b['mean'][q]) == pytest.approx(float(a['mean'][q]), rel=1e-6)
+        assert float(b['var'][q]) == pytest.approx(float(a['var'][q]), rel=1e-4)
+    print('largest |S_fp32 - S_fp64| over all indices:', worst)
+    assert worst < 2e-4
