@@ -309,6 +309,9 @@ __device__ __forceinline__ SampleIn<true> generate_sample(const McDesign& mc, lo
 //               densities there (csrc/pem_likelihood.hip's formula); nothing but scalars leaves the chip
 //            4: fused compression -- latent = norm(j_ion) @ basis (csrc/pem_svd.hip's formula) accumulated from the
 //               registers of the angle loop: the profile is neither staged nor stored
+//            5: fused compression, staged -- norm(j_ion) goes to the LDS tile as the profile does in mode 1, and the round's
+//               16 x 91 by 91 x 8 product runs on v_mfma_f64_16x16x4_f64 (the matrix pipe beside the VALU, no basis reads
+//               in the angle loop)
 // LDS map (doubles): shared by the workgroup: simpson[96][2] | dpoly[32*12];  per wave: params[NROWS][64] |
 // tile[S*91] | 2 (sink).  The Simpson table is padded with zero weights to L*CH <= 96 entries so the angle loop
 // needs no branch.  The den/num partial sums of a round reuse the rows of `params` that the round has consumed.
@@ -324,7 +327,7 @@ constexpr int QPOLY_DOUBLES = (PEM_NDI + PEM_NQB) * PEM_NDC * 2;
 template <int L, int JMODE>
 constexpr int wave_lds_doubles() {
     return param_rows<L>() * WAVE +
-           ((JMODE == 1 || JMODE == 3) ? (WAVE / L) * NANG + 2 : JMODE == 2 ? ((WAVE / L) * NANG + 4) / 2 : 0);
+           ((JMODE == 1 || JMODE == 3 || JMODE == 5) ? (WAVE / L) * NANG + 2 : JMODE == 2 ? ((WAVE / L) * NANG + 4) / 2 : 0);
 }
 template <int L, int JMODE>
 constexpr int fast_lds_doubles() { return TABLE_DOUBLES + WPB * wave_lds_doubles<L, JMODE>(); }
@@ -337,6 +340,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 // 16-byte store of the write-once profile stream.  Non-temporal: measured 227.6 -> 190.7 us per 1.25e6-sample
 // launch against plain stores, interleaved A/B (tools/ab_bench.py); the same hint on the small input
@@ -458,6 +462,7 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
     constexpr int TILE = S * NANG;          // profile values per round tile
     constexpr bool WRITE_J = JMODE != 0 && JMODE != 4;
     constexpr bool LATENT = JMODE == 4;
+    constexpr bool STAGED_LAT = JMODE == 5;      // WRITE_J with norm(j_ion) in the tile instead of j_ion
     using JT = typename std::conditional<JMODE == 2, float, double>::type;   // element type of the stored profile
     constexpr int PER16 = 16 / (int)sizeof(JT);                              // values per 16-byte piece
     constexpr int PAIRS = TILE / PER16;     // 16-byte pieces of a full round tile (TILE divides evenly)
@@ -593,10 +598,28 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
                     rr2 *= q2;
                 }
             }
+            if constexpr (STAGED_LAT) {
+                // rolled like the register-accumulating form above, and for the same reason (23 inlined log10)
+#pragma unroll LATENT_UNROLL
+                for (int j = 0; j < CH; ++j) {
+                    const double2 w = my_w[j];
+                    const double f = X1 + X2;
+                    const double ji = f + jcex;
+                    const bool in_range = k0 + j < NANG;
+                    lo = fmin(lo, in_range ? ji : __builtin_inf());
+                    den = fma(w.x, f, den);
+                    num = fma(w.y, f, num);
+                    tile[in_range ? s * NANG + k0 + j : TILE] = io.log_norm ? pem::pem_log10(ji) : ji;
+                    X1 *= rr1;
+                    rr1 *= q1;
+                    X2 *= rr2;
+                    rr2 *= q2;
+                }
+            }
 #pragma unroll
-            for (int j = 0; WRITE_J && j < PF && j < CH; ++j) wq[j] = my_w[j];
+            for (int j = 0; WRITE_J && !STAGED_LAT && j < PF && j < CH; ++j) wq[j] = my_w[j];
 #pragma unroll
-            for (int j = 0; !LATENT && j < CH; ++j) {
+            for (int j = 0; !LATENT && !STAGED_LAT && j < CH; ++j) {
                 if constexpr (!WRITE_J) wq[j] = my_w[j];   // no tile stores in between: the compiler schedules the reads
                 else if (j + PF < CH) wq[j + PF] = my_w[j + PF];
                 const double f = X1 + X2;     // j_beam + j_scat
@@ -631,6 +654,10 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
                         den = ex.den;
                         num = ex.num;
                         lo = ex.lo;
+                        if constexpr (STAGED_LAT) {   // exact_chunk left j_ion in the tile: the staged form wants its norm
+                            if (io.log_norm)
+                                for (int j = 0; j < CH && k0 + j < NANG; ++j) tile[s * NANG + k0 + j] = pem::pem_log10((double)tile[s * NANG + k0 + j]);
+                        }
                         if constexpr (LATENT) {
                             static_assert(LAT_RT == 8, "LatSums carries eight latent columns");
                             const LatSums el = exact_latents(X1a, X2a, jcex, a1s, a2s, k0, CH, m.basis + k0 * LAT_RT, io.log_norm);
@@ -665,11 +692,43 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
             }
             if constexpr (WRITE_J) {
                 if ((bad >> s) & 1) {  // plume.py:106: the whole profile of an invalid sample becomes 1e-20 (rare)
+                    const JT fill = (JT)((STAGED_LAT && io.log_norm) ? -20.0 : 1e-20);
                     for (int j = 0; j < CH; ++j)
-                        if (k0 + j < NANG) tile[s * NANG + k0 + j] = (JT)1e-20;
+                        if (k0 + j < NANG) tile[s * NANG + k0 + j] = fill;
                 }
                 wave_lds_sync();
                 const long long first = t * WAVE + (long long)round * S;
+                if constexpr (STAGED_LAT) {
+                    static_assert(!STAGED_LAT || (L == 4 && LAT_RT == 8), "a round is 16 samples: the rows of one 16x16x4 tile");
+                    // latent[16 samples][8 columns] = tile[16][91] @ basis[91][8] on the matrix pipe: lane (s = row, c = quad) feeds
+                    // A[row][4 step + quad] = tile[row][k] and B[4 step + quad][column = row] (zero for columns 8..15)
+                    const double* ap = reinterpret_cast<const double*>(tile) + s * NANG + c;
+                    const bool bcol = s < LAT_RT;
+                    const double* bp = m.basis + c * LAT_RT + (bcol ? s : 0);
+                    f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int step = 0; step < 22; step += 2) {
+                        const double a0 = ap[4 * step], a1 = ap[4 * step + 4];
+                        const double b0 = bcol ? bp[4 * step * LAT_RT] : 0.0, b1 = bcol ? bp[(4 * step + 4) * LAT_RT] : 0.0;
+                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
+                    }
+                    {   // step 22: k = 88 + quad, k = 91 does not exist (masked: 0 * inf would be NaN)
+                        const double a = 88 + c < NANG ? ap[88] : 0.0;
+                        const double b = bcol ? bp[88 * LAT_RT] : 0.0;
+                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc0, 0, 0, 0);
+                    }
+                    // lane (row, quad) holds D[quad + 4 i][column = row]
+                    if (s < io.rank) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const long long smp_g = first + c + 4 * i;
+                            if (FULL || smp_g < io.n) io.latent[smp_g * io.rank + s] = acc0[i] + acc1[i];
+                        }
+                    }
+                    wave_lds_sync();
+                    continue;
+                }
                 if constexpr (JMODE == 3) {
                     static_assert(JMODE != 3 || 2 * L < param_rows<L>(), "row 2L of `params` carries the likelihood sum");
                     // measured current densities against the staged profile: lane (s, c) takes measurements c, c+L, ...
@@ -797,7 +856,7 @@ void plume_r1_kernel(PlumeIO io, CoupledIO cio, long long ntiles, DesignArg<MC> 
         m.qpoly = reinterpret_cast<const double2*>(q);
     }
     m.basis = nullptr;
-    if constexpr (JMODE == 4) {   // zero-padded basis [96][LAT_RT] + column sums, behind the per-wave regions
+    if constexpr (JMODE == 4 || JMODE == 5) {   // zero-padded basis [96][LAT_RT] + column sums, behind the per-wave regions
         double* bas = lds + TABLE_DOUBLES + WPB * wave_lds_doubles<L, JMODE>();
         for (int i = tid; i < 96 * LAT_RT; i += WAVE * WPB) {
             const int k = i / LAT_RT, r = i - k * LAT_RT;
@@ -1227,6 +1286,268 @@ __global__ __launch_bounds__(BLOCK) void plume_radii_small_kernel(PlumeIO io, Ra
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// FEW radii by recurrence: the R = 1 fast path generalised (2 <= R <= RADII_SMALL).  The two kernels above are bound by
+// LATENCY, not by issue or HBM: a wave has one sample in flight, and every sample is a chain Gaussians -> LDS -> wave
+// reduction -> LDS -> block stream (5.4k cycles per sample measured at R = 2 where the instruction count says 1.3k:
+// profiles/radii_probe_r02e.txt).  Here a wave works on 8 samples at a time as plume_r1_kernel does: lane (s, c) walks
+// angles k = 12 c .. 12 c + 11 of sample s, advancing the two Gaussians by the two-term recurrence (4 multiplies per
+// angle) from chunk starts that come from the same recurrence at stride 12; per angle it forms the R values
+// b1[r] e1 + b2[r] e2 + j_cex[r] from amplitudes it holds in registers and stores them -- R consecutive doubles of j_ion --
+// straight from the loop.  The Simpson functionals of the two Gaussians ride along (4 FMAs per angle) and are folded over
+// the 8 chunk lanes; cos_div / arccos / T_c of all (sample, radius) pairs of the 64-sample tile follow, one lane per pair.
+// "Equal to the reference" in the deep tail is kept as in the R = 1 path: a chunk with a value below 1e-290 (or <= 0, or
+// a non-finite amplitude) is re-evaluated literally with direct exp(); amplitudes of opposite sign or near overflow send
+// the pair's divergence integrals through the literal angle-by-angle sum.
+// LDS (doubles): shared: simpson[96][2] | dpoly[384];  per wave: params[8][64] | sums[64][4] | PB[64][R][3]
+// ---------------------------------------------------------------------------------------------
+constexpr int RF_L = 8, RF_S = WAVE / RF_L, RF_CH = 12;
+static_assert(RF_L * RF_CH >= NANG && RF_L * RF_CH <= NSIMP, "8 chunks of 12 angles cover the 91-point grid inside the padded table");
+
+template <int R>   // the number of radii is a compile-time constant: amplitudes and the values of two angles live in registers
+__global__ __launch_bounds__(WAVE * WPB) void plume_rfew_kernel(PlumeIO io, RadiiSmallArg radii_arg) {
+    constexpr int RM = R;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* lds = reinterpret_cast<double*>(smem_raw);
+    double2* tab_simpson = reinterpret_cast<double2*>(lds);
+    double* tab_poly = lds + 2 * NSIMP;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int per_wave = 8 * WAVE + 4 * WAVE + 3 * WAVE * R;
+    double* params = lds + TABLE_DOUBLES + wave * per_wave;     // rows: a1 a2 | r0 G E (beam 1) | r0 G E (beam 2)
+    double* sums = params + 8 * WAVE;                           // [64][4] {s1d, s1n, s2d, s2n}
+    double* PB = sums + 4 * WAVE;                               // [64][R][3] {b1, b2, j_cex}
+    for (int i = tid; i < NSIMP; i += WAVE * WPB)
+        tab_simpson[i] = i < NANG ? make_double2(PEM_SIMPSON_CDEN[i], PEM_SIMPSON_CNUM[i]) : make_double2(0.0, 0.0);
+    for (int i = tid; i < PEM_NDI * PEM_NDC; i += WAVE * WPB) tab_poly[i] = PEM_DPOLY[i];
+    __syncthreads();
+
+    const int s = lane % RF_S, c = lane / RF_S, k0 = c * RF_CH;
+    const double2* my_w = tab_simpson + k0;
+    const bool have_T = io.T != nullptr;
+    const long long ntiles = (io.n + WAVE - 1) / WAVE;
+    const long long nwaves = (long long)gridDim.x * WPB;
+    const size_t blk = (size_t)NANG * R;
+    for (long long t = (long long)blockIdx.x * WPB + wave; t < ntiles; t += nwaves) {
+        const int in_tile = (int)(io.n - t * WAVE < WAVE ? io.n - t * WAVE : WAVE);
+        const long long gl = lane < in_tile ? t * WAVE + lane : io.n - 1;     // idle lanes repeat the last sample
+        // ------------------------------ prelude: one lane per sample ------------------------------
+        unsigned literal_l = 0;
+        {
+            const double c0_l = io.c0[gl];
+            const PlumeSetup ps = plume_setup(io.P_b[gl], io.c1[gl], io.c2[gl], io.c3[gl], io.c4[gl], io.c5[gl], io.torr2pa);
+            const double sigma_l = io.sigma[gl], IB0_l = io.I_B0[gl];
+            const double u1 = 1.0 / (ps.a1 * ps.a1), u2 = 1.0 / (ps.a2 * ps.a2);
+            const double A1 = (1.0 - c0_l) / normaliser(ps.a1, u1, tab_poly);
+            const double A2 = c0_l / normaliser(ps.a2, u2, tab_poly);
+            const double s1 = (GRID_H * GRID_H) * u1, s2 = (GRID_H * GRID_H) * u2;
+            params[0 * WAVE + lane] = ps.a1;
+            params[1 * WAVE + lane] = ps.a2;
+            params[2 * WAVE + lane] = exp_nonpos(-s1);
+            params[3 * WAVE + lane] = exp_nonpos(-(2.0 * RF_CH) * s1);
+            params[4 * WAVE + lane] = exp_nonpos(-(double)(RF_CH * RF_CH) * s1);
+            params[5 * WAVE + lane] = exp_nonpos(-s2);
+            params[6 * WAVE + lane] = exp_nonpos(-(2.0 * RF_CH) * s2);
+            params[7 * WAVE + lane] = exp_nonpos(-(double)(RF_CH * RF_CH) * s2);
+            for (int r = 0; r < R; ++r) {
+#pragma clang fp contract(off)
+                const double rad = radii_arg.r[r];
+                const double decay = exp(-rad * ps.n_neutral * sigma_l);
+                const double j_cex = IB0_l * (1.0 - decay) / (2.0 * PEM_PI * (rad * rad));
+                const double base = IB0_l * decay / (rad * rad);
+                const double b1 = base * A1, b2 = base * A2;
+                double* pb = PB + (lane * R + r) * 3;
+                pb[0] = b1;
+                pb[1] = b2;
+                pb[2] = j_cex;
+                if (!(fabs(b1) + fabs(b2) < 1e300) || ((b1 < 0.0) != (b2 < 0.0) && b1 != 0.0 && b2 != 0.0)) literal_l |= 1u << r;
+            }
+        }
+        const unsigned long long a1_nonpos = __ballot(params[0 * WAVE + lane] <= 0.0);
+        wave_lds_sync();
+        unsigned long long inv_mask = 0;
+        // ------------------------------ rounds: 8 samples, 8 chunk lanes each ------------------------------
+        for (int round = 0; round < RF_L; ++round) {
+            const int smp = round * RF_S + s;
+            const long long g = t * WAVE + smp;
+            const bool exists = smp < in_tile;
+            const double r01 = params[2 * WAVE + smp], G1 = params[3 * WAVE + smp], E1 = params[4 * WAVE + smp];
+            const double r02 = params[5 * WAVE + smp], G2 = params[6 * WAVE + smp], E2 = params[7 * WAVE + smp];
+            double b1[RM], b2[RM], jc[RM];
+            bool finite = true;
+#pragma unroll
+            for (int r = 0; r < RM; ++r) {
+                const double* pb = PB + (smp * R + (r < R ? r : 0)) * 3;
+                b1[r] = pb[0];
+                b2[r] = pb[1];
+                jc[r] = pb[2];
+                finite = finite && __builtin_isfinite(b1[r]) && __builtin_isfinite(b2[r]);
+            }
+            // chunk start k0 = 12 c by the coarse recurrence: e_{k0} = E^(c^2), r_{k0} = r0 G^c
+            double e1 = 1.0, e2 = 1.0, rr1 = r01, rr2 = r02, rho1 = E1, rho2 = E2;
+            if (params[0 * WAVE + smp] == 0.0) e1 = e2 = __builtin_nan("");   // alpha1 = 0: exp(-(0/0)^2) is NaN in the reference
+            const double E1sq = E1 * E1, E2sq = E2 * E2;
+#pragma unroll
+            for (int i = 0; i < RF_L - 1; ++i) {
+                if (i < c) {
+                    e1 *= rho1;
+                    rho1 *= E1sq;
+                    rr1 *= G1;
+                    e2 *= rho2;
+                    rho2 *= E2sq;
+                    rr2 *= G2;
+                }
+            }
+            const double q1 = r01 * r01, q2 = r02 * r02;
+            double part[4] = {0.0, 0.0, 0.0, 0.0}, lo = __builtin_inf();
+            double* dst = io.j_ion + (size_t)g * blk + (size_t)k0 * R;
+            // The chunk's values are one run of 12 R consecutive doubles of j_ion.  Two angles = 2 R doubles per iteration,
+            // stored as R 16-byte pieces.  For an odd R the run of an odd sample starts at an odd double (the start is
+            // (g 91 + 12 c) R doubles into a 16-byte aligned array): such a lane stores its first double on its own, then
+            // pieces shifted by one element (the last element of an iteration is carried into the next), and the last
+            // double on its own again -- selected per lane, so that every 16-byte store has all 64 lanes in it.
+            const bool mis = (R & 1) && (smp & 1);
+            double carry = 0.0;
+#pragma unroll 1
+            for (int jj = 0; jj < RF_CH; jj += 2) {
+                double ev[2 * RM];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const double2 w = my_w[jj + h];
+#pragma unroll
+                    for (int r = 0; r < RM; ++r) ev[h * RM + r] = fma(b1[r], e1, b2[r] * e2) + jc[r];
+                    part[0] = fma(w.x, e1, part[0]);
+                    part[1] = fma(w.y, e1, part[1]);
+                    part[2] = fma(w.x, e2, part[2]);
+                    part[3] = fma(w.y, e2, part[3]);
+                    e1 *= rr1;
+                    rr1 *= q1;
+                    e2 *= rr2;
+                    rr2 *= q2;
+                }
+                double* d = dst + (size_t)jj * R;
+                if (k0 + jj + 1 < NANG) {                  // both angles exist (all but the last iterations of the last chunk)
+#pragma unroll
+                    for (int i = 0; i < 2 * RM; ++i) lo = fmin(lo, ev[i]);
+                    if (exists) {
+                        if constexpr ((R & 1) == 0) {
+#pragma unroll
+                            for (int q = 0; q < RM; ++q) *reinterpret_cast<f64x2*>(d + 2 * q) = f64x2{ev[2 * q], ev[2 * q + 1]};
+                        } else {
+                            if (mis && jj == 0) d[0] = ev[0];
+#pragma unroll
+                            for (int q = 0; q < RM; ++q) {
+                                f64x2 pr;
+                                pr.x = mis ? (q == 0 ? carry : ev[2 * q - 1]) : ev[2 * q];
+                                pr.y = mis ? ev[2 * q] : ev[2 * q + 1];
+                                if (!(mis && jj == 0 && q == 0)) *reinterpret_cast<f64x2*>(d + 2 * q - (mis ? 1 : 0)) = pr;
+                            }
+                            carry = ev[2 * RM - 1];
+                            if (mis && jj + 2 >= RF_CH) d[2 * RM - 1] = carry;      // the run ends here: its last double
+                        }
+                    }
+                } else {                                   // past 90 degrees: at most the first angle of the pair exists
+                    if (k0 + jj < NANG) {
+#pragma unroll
+                        for (int r = 0; r < RM; ++r) lo = fmin(lo, ev[r]);
+                        if (exists) {
+                            if ((R & 1) && mis && jj > 0) d[-1] = carry;           // the carried double of the iteration before
+#pragma unroll
+                            for (int r = 0; r < RM; ++r) d[r] = ev[r];
+                        }
+                    } else if ((R & 1) && mis && exists && jj > 0 && k0 + jj - 1 < NANG) {
+                        d[-1] = carry;
+                    }
+                    carry = 0.0;
+                    // (nothing further of this chunk exists; the recurrence runs on harmlessly)
+                }
+            }
+            // deep tail: where the reference's own exp() has left the normal range the chunk is evaluated literally
+            const bool uncertain = lo < 1e-290 || !finite;
+            if (__ballot(uncertain)) {
+                if (uncertain) {
+#pragma clang fp contract(off)
+                    const double a1s = params[0 * WAVE + smp], a2s = params[1 * WAVE + smp];
+                    part[0] = part[1] = part[2] = part[3] = 0.0;
+                    lo = __builtin_inf();
+                    for (int j = 0; j < RF_CH; ++j) {
+                        const int k = k0 + j;
+                        if (k >= NANG) break;
+                        const double alpha = k == NANG - 1 ? HALF_PI : (double)k * GRID_H;
+                        const double t1 = alpha / a1s, t2 = alpha / a2s;
+                        const double g1 = exp(-(t1 * t1)), g2 = exp(-(t2 * t2));
+                        for (int r = 0; r < R; ++r) {
+                            const double* pb = PB + (smp * R + r) * 3;
+                            const double ji = (pb[0] * g1 + pb[1] * g2) + pb[2];
+                            lo = fmin(lo, ji);
+                            if (exists) dst[(size_t)j * R + r] = ji;
+                        }
+                        part[0] = __builtin_fma(my_w[j].x, g1, part[0]);
+                        part[1] = __builtin_fma(my_w[j].y, g1, part[1]);
+                        part[2] = __builtin_fma(my_w[j].x, g2, part[2]);
+                        part[3] = __builtin_fma(my_w[j].y, g2, part[3]);
+                    }
+                }
+            }
+            // fold the 8 chunk lanes of a sample: Simpson functionals and plume.py:105
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int sh = RF_S; sh < WAVE; sh <<= 1) part[q] += __shfl_xor(part[q], sh);
+            }
+            if (c == 0) {
+                f64x2* sv = reinterpret_cast<f64x2*>(sums + smp * 4);
+                sv[0] = f64x2{part[0], part[1]};
+                sv[1] = f64x2{part[2], part[3]};
+            }
+            unsigned long long bad = __ballot(lo <= 0.0);
+#pragma unroll
+            for (int sh = RF_S; sh < WAVE; sh <<= 1) bad |= bad >> sh;
+            bad = (bad | (a1_nonpos >> (round * RF_S))) & ((1ull << RF_S) - 1);
+            inv_mask |= bad << (round * RF_S);
+            if (((bad >> s) & 1) && exists) {   // plume.py:106: the whole block of an invalid sample becomes 1e-20 (rare)
+                for (int j = 0; j < RF_CH; ++j)
+                    if (k0 + j < NANG)
+                        for (int r = 0; r < R; ++r) dst[(size_t)j * R + r] = 1e-20;
+            }
+        }
+        wave_lds_sync();
+        if (io.invalid && lane < in_tile) io.invalid[t * WAVE + lane] = (uint8_t)((inv_mask >> lane) & 1);
+        // ------------------------------ postlude: one lane per (sample, radius) pair ------------------------------
+        const int pairs = in_tile * R;
+        for (int idx = lane; idx < pairs; idx += WAVE) {
+            const int smp = idx / R, r = idx - smp * R;
+            const unsigned literal = (unsigned)__shfl((int)literal_l, smp);
+            const double* pb = PB + idx * 3;
+            const double* sv = sums + smp * 4;
+            double num, den;
+            {
+#pragma clang fp contract(off)
+                num = pb[0] * sv[1] + pb[1] * sv[3];
+                den = pb[0] * sv[0] + pb[1] * sv[2];
+            }
+            if ((literal >> r) & 1) {   // the reference's own summation order (amplitudes of opposite sign / near overflow)
+#pragma clang fp contract(off)
+                const double a1s = params[0 * WAVE + smp], a2s = params[1 * WAVE + smp];
+                num = 0.0;
+                den = 0.0;
+                for (int k = 0; k < NANG; ++k) {
+                    const double alpha = k == NANG - 1 ? HALF_PI : (double)k * GRID_H;
+                    const double t1 = alpha / a1s, t2 = alpha / a2s;
+                    const double f = pb[0] * exp(-(t1 * t1)) + pb[1] * exp(-(t2 * t2));
+                    den = __builtin_fma(tab_simpson[k].x, f, den);
+                    num = __builtin_fma(tab_simpson[k].y, f, num);
+                }
+            }
+            double cos_div = num / den;
+            if (cos_div == __builtin_inf()) cos_div = __builtin_nan("");
+            const long long g = t * WAVE + smp;
+            io.div[(size_t)g * R + r] = acos(cos_div);
+            if (have_T) io.Tc[(size_t)g * R + r] = io.T[g] * cos_div;
+        }
+        wave_lds_sync();   // params / sums / PB are rewritten by the next tile
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void cathode_kernel(long long n, const double* __restrict__ P_b,
                                                         const double* __restrict__ V_a, const double* __restrict__ T_e,
                                                         const double* __restrict__ V_vac,
@@ -1374,7 +1695,7 @@ template <int L, bool COUPLED, int JMODE, bool MC = false>
 int launch_r1(const PlumeIO& io, const CoupledIO& cio, hipStream_t st, const McDesign& mc = McDesign{}) {
     size_t lds = (size_t)fast_lds_doubles<L, JMODE>() * 8;
     if (JMODE == 3) lds += (size_t)io.n_cond * (io.n_ang | 1) * 32;
-    if (JMODE == 4) lds += (size_t)(96 + 1) * LAT_RT * 8;
+    if (JMODE == 4 || JMODE == 5) lds += (size_t)(96 + 1) * LAT_RT * 8;
     if (JMODE == 0) lds += (size_t)QPOLY_DOUBLES * 8;
     const long long ntiles = (io.n + WAVE - 1) / WAVE;
     unsigned grid = 0;
@@ -1633,6 +1954,26 @@ int pem_plume_f64_dev(size_t n, int n_radii, const double* radii, double torr2pa
     PlumeIO io{(long long)n, torr2pa, radii[0], P_b, c0, c1, c2, c3, c4, c5, sigma_cex, I_B0, T, j_ion, div_angle, T_c, invalid};
     if (n_radii == 1 && aligned16(j_ion)) return dispatch_lanes<false, 1>(io, CoupledIO{}, st);
 
+    if (n_radii >= 2 && n_radii <= RADII_SMALL && aligned16(j_ion) && !getenv("PEM_RADII_GENERAL") && !getenv("PEM_RADII_SMALL")) {
+        // few radii: eight samples per wave in flight, Gaussians by recurrence, profile stored from the angle loop
+        RadiiSmallArg ra;
+        for (int r = 0; r < RADII_SMALL; ++r) ra.r[r] = r < n_radii ? radii[r] : 1.0;
+        const size_t lds = (size_t)(TABLE_DOUBLES + WPB * (12 * WAVE + 3 * WAVE * n_radii)) * 8;
+        const long long ntiles = (long long)((n + WAVE - 1) / WAVE);
+        unsigned grid = 0;
+        if (int rc = fast_grid((long long)(160 * 1024 / lds) < 3 ? (long long)(160 * 1024 / lds) : 3, ntiles, &grid)) return rc;
+        switch (n_radii) {
+            case 2: hipLaunchKernelGGL(plume_rfew_kernel<2>, dim3(grid), dim3(WAVE * WPB), lds, st, io, ra); break;
+            case 3: hipLaunchKernelGGL(plume_rfew_kernel<3>, dim3(grid), dim3(WAVE * WPB), lds, st, io, ra); break;
+            case 4: hipLaunchKernelGGL(plume_rfew_kernel<4>, dim3(grid), dim3(WAVE * WPB), lds, st, io, ra); break;
+            case 5: hipLaunchKernelGGL(plume_rfew_kernel<5>, dim3(grid), dim3(WAVE * WPB), lds, st, io, ra); break;
+            case 6: hipLaunchKernelGGL(plume_rfew_kernel<6>, dim3(grid), dim3(WAVE * WPB), lds, st, io, ra); break;
+            case 7: hipLaunchKernelGGL(plume_rfew_kernel<7>, dim3(grid), dim3(WAVE * WPB), lds, st, io, ra); break;
+            default: hipLaunchKernelGGL(plume_rfew_kernel<8>, dim3(grid), dim3(WAVE * WPB), lds, st, io, ra); break;
+        }
+        HIP_TRY(hipGetLastError());
+        return PEM_OK;
+    }
     if (n_radii >= 2 && n_radii <= RADII_SMALL && !getenv("PEM_RADII_GENERAL")) {
         // few radii: the per-radius work of a whole tile at once (R = 2..5: 1.2-2.0 -> ~3 TB/s of output, tools/radii_probe.py)
         RadiiSmallArg ra;
@@ -1765,7 +2106,11 @@ int pem_coupled_latent_f64_dev(size_t n, double torr2pa, double radius, const do
     PlumeIO io{(long long)n, torr2pa, radius, P_b, c0, c1, c2, c3, c4, c5, sigma_cex, nullptr, nullptr, nullptr, div_angle, T_c, invalid, nullptr,
                nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, basis, latent, rank, norm == PEM_NORM_LOG10 ? 1 : 0};
     CoupledIO cio{V_a, T_e, V_vac, Pstar, P_T, mdot_a, a_1, V_cc, nullptr, nullptr};
-    return launch_r1<4, true, 4>(io, cio, static_cast<hipStream_t>(stream));
+    // two forms of the fused compression: 5 = profile norm staged in LDS + MFMA contraction, 4 = latents
+    // accumulated in the registers of the angle loop
+    static const int latent_mode = getenv("PEM_LATENT_MODE") ? atoi(getenv("PEM_LATENT_MODE")) : 5;
+    if (latent_mode == 4) return launch_r1<4, true, 4>(io, cio, static_cast<hipStream_t>(stream));
+    return launch_r1<4, true, 5>(io, cio, static_cast<hipStream_t>(stream));
 }
 
 // ---- coupled, mixed precision: fp64 arithmetic, the 91-point profile stored as fp32 -----------------

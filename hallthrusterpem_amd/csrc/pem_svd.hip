@@ -224,6 +224,59 @@ __global__ __launch_bounds__(BLOCK) void svd_compress_kernel(long long n, int do
     }
 }
 
+// compress with the log10 norm, dof <= 96: no LDS tile at all.  A lane loads the values it will feed to the matrix pipe
+// straight from `field` in the operand layout of v_mfma_f64_16x16x4_f64 -- lane (row, quad) takes field[sample row][4 step
+// + quad], steps 0..23: per instruction 16 rows x 32 contiguous bytes, every byte of the tile loaded exactly once -- takes
+// their log10 in registers (table version, the only LDS traffic left) and issues the 16 x 4 by 4 x 16 products against
+// basis rows it keeps in registers for the whole launch.  Against the tiled kernel above that removes the transposition
+// through LDS (12 16-byte writes and 23 reads per lane and tile) and with it the 47 KB of tiles per workgroup that held the
+// kernel at two waves per SIMD: this one is limited by its ~140 registers (three waves per SIMD), so one wave's loads are
+// in flight while the others take logs.
+constexpr int DIRECT_STEPS = 24;     // dof <= 96
+__global__ __launch_bounds__(BLOCK) void svd_compress_log10_direct_kernel(long long n, int dof, int r,
+                                                                         const double* __restrict__ field,
+                                                                         const double* __restrict__ basis,
+                                                                         double* __restrict__ latent) {
+    __shared__ __attribute__((aligned(16))) double logtab[pem::LOG_TABLE_DOUBLES];
+    pem::load_log_table(logtab, threadIdx.x, BLOCK);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = lane & 15, quad = lane >> 4;
+    // B[4 step + quad][column = row] = basis[k][row], zero past the rank and past dof
+    double b[DIRECT_STEPS];
+#pragma unroll
+    for (int step = 0; step < DIRECT_STEPS; ++step) {
+        const int k = 4 * step + quad;
+        b[step] = (k < dof && row < r) ? basis[(size_t)k * r + row] : 0.0;
+    }
+    const long long ntiles = (n + 15) / 16;
+    const long long stride = (long long)gridDim.x * WAVES;
+    for (long long t = (long long)blockIdx.x * WAVES + wave; t < ntiles; t += stride) {
+        const long long s0 = t * 16;
+        const long long smp = s0 + row < n ? s0 + row : n - 1;         // rows past the batch repeat its last sample
+        const double* src = field + smp * dof + quad;
+        double a[DIRECT_STEPS];
+#pragma unroll
+        for (int step = 0; step < DIRECT_STEPS; ++step) a[step] = 4 * step + quad < dof ? src[4 * step] : 1.0;
+        f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int step = 0; step < DIRECT_STEPS; step += 2) {
+            // k >= dof: the value is 0 AFTER the norm (log10(1) = 0 exactly, and it meets a zero basis row)
+            const double l0 = pem::pem_log10_tab(a[step], logtab), l1 = pem::pem_log10_tab(a[step + 1], logtab);
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(l0, b[step], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(l1, b[step + 1], acc1, 0, 0, 0);
+        }
+        // lane (row, quad) holds D[sample quad + 4 i][column = row]
+        if (row < r) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const long long sg = s0 + quad + 4 * i;
+                if (sg < n) latent[sg * r + row] = acc0[i] + acc1[i];
+            }
+        }
+    }
+}
+
 // LDS: basis_t[16][dof_p] with dof_p = 16*ceil(dof/16) (zero padded) | per wave: tile[16*dof] (+2)
 template <int MODE>
 __global__ __launch_bounds__(BLOCK) void svd_reconstruct_kernel(long long n, int dof, int r, double scale,
@@ -344,6 +397,14 @@ int pem_svd_compress_f64_dev(size_t n, int dof, int rank, int norm, double norm_
         else if (norm == PEM_NORM_LINEAR) PEM_SVD_LAUNCH(ROWS_, UN_, RT_, PEM_NORM_LINEAR); \
         else PEM_SVD_LAUNCH(ROWS_, UN_, RT_, PEM_NORM_NONE);                                \
     } while (0)
+    if (norm == PEM_NORM_LOG10 && dof <= 4 * DIRECT_STEPS && !getenv("PEM_SVD_TILED")) {
+        size_t dblocks = ((n + 15) / 16 + WAVES - 1) / WAVES;
+        if (dblocks > 256 * 3) dblocks = 256 * 3;     // persistent: three workgroups (12 waves) per CU by registers
+        hipLaunchKernelGGL(svd_compress_log10_direct_kernel, dim3((unsigned)dblocks), dim3(BLOCK), 0, static_cast<hipStream_t>(stream),
+                           (long long)n, dof, rank, field, basis, latent);
+        HIP_TRY(hipGetLastError());
+        return PEM_OK;
+    }
     const int rt = rank <= 4 ? 4 : (rank <= 8 ? 8 : 16);
     if (dof <= 96) {
         if (rt == 4) PEM_SVD_BY_MODE(16, 12, 4); else if (rt == 8) PEM_SVD_BY_MODE(16, 12, 8); else PEM_SVD_BY_MODE(16, 12, 16);

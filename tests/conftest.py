@@ -44,8 +44,9 @@ def div_err(got, want, cos_ulps=8):
     """Error metric for div_angle = arccos(cos_div) (plume.py:127).
 
     arccos is ill-conditioned at cos_div -> 1 (beams narrower than the 1-degree grid): one ulp of
-    cos_div moves the angle by 1.1e-16/sin(angle).  An entry whose angle error is within `cos_ulps`
-    ulps of cos_div counts as exact; otherwise its relative angle error is returned.
+    cos_div moves the angle by 1.1e-16/sin(angle), and by sqrt(2.2e-16) at the pole itself.  An entry whose
+    cosine is within `cos_ulps` ulps of the reference's counts as exact; otherwise its relative angle error
+    is returned.
     """
     got = np.asarray(got, dtype=np.float64)
     want = np.asarray(want, dtype=np.float64)
@@ -56,7 +57,8 @@ def div_err(got, want, cos_ulps=8):
         return 0.0
     d = np.abs(got[fin] - want[fin])
     w = np.abs(want[fin])
-    in_cos_noise = d * np.maximum(np.sin(w), d) <= cos_ulps * 1.1102230246251565e-16
+    # |cos(got) - cos(want)| = 2 |sin((got + want) / 2) sin((got - want) / 2)|: exact also at the pole, where it is d^2 / 2
+    in_cos_noise = 2.0 * np.abs(np.sin(0.5 * (got[fin] + want[fin])) * np.sin(0.5 * (got[fin] - want[fin]))) <= cos_ulps * 1.1102230246251565e-16
     rel = np.where(in_cos_noise, 0.0, d / np.where(w == 0, 1.0, w))
     return float(rel.max())
 

@@ -103,7 +103,7 @@ def j_ion_error(got, want, bounds, what='j_ion'):
 
 def divergence_error(got_div, want_div, got_tc, want_tc, bounds, what='div_angle'):
     """div_angle = arccos(cos_div) and T_c = T cos_div against the bound on cos_div.  An angle passes if it is within TOL
-    relative, or if its error maps back (d cos = sin(angle) d angle; d^2 at the pole, conservatively) into the allowed
+    relative, or if its error maps back -- |cos(got) - cos(want)|, evaluated without cancellation -- into the allowed
     error of cos_div.  dict(err_div, err_tc, cond, n_cancelling, tau_seen): errors scaled so that <= TOL passes; cond =
     the largest condition number among the pairs that needed the bound; tau_seen = the largest relative T_c error per unit
     of (cond_den + cond_num - 2) among them."""
@@ -121,7 +121,8 @@ def divergence_error(got_div, want_div, got_tc, want_tc, bounds, what='div_angle
         d = np.abs(gd - wd)
         fin = ok & np.isfinite(wd) & np.isfinite(gd)
         rel = d / np.where(wd == 0, 1.0, np.abs(wd))
-        in_bound = d * np.maximum(np.abs(np.sin(wd)), d) <= dcos
+        # |cos(got) - cos(want)| = 2 |sin((got + want) / 2) sin((got - want) / 2)|, exact also at the pole (where it is d^2 / 2)
+        in_bound = 2.0 * np.abs(np.sin(0.5 * (gd + wd)) * np.sin(0.5 * (gd - wd))) <= dcos
         excess = np.where(fin & ~in_bound, rel, 0.0)
         needed = fin & in_bound & (rel > TOL) & (bounds['cos_rel'] > 4 * EPS * 1.5)
         out['err_div'] = float(np.max(excess, initial=0.0))

@@ -22,7 +22,15 @@ def find(pattern):
 
 # ---- kernel trace: per-kernel durations -------------------------------------------------------------
 durs = defaultdict(list)
+full_durs = []
 for f in find('*kernel_trace.csv'):
+    if 'trace_full' in str(f):     # the whole-config pass: only its long launches of the coupled kernel are of interest
+        with open(f) as fd:
+            for row in csv.DictReader(fd):
+                d = int(row['End_Timestamp']) - int(row['Start_Timestamp'])
+                if KERNEL in row['Kernel_Name'] and d > 1_000_000:
+                    full_durs.append(d)
+        continue
     with open(f) as fd:
         for row in csv.DictReader(fd):
             durs[row['Kernel_Name']].append(int(row['End_Timestamp']) - int(row['Start_Timestamp']))
@@ -35,7 +43,11 @@ for k, v in sorted(durs.items(), key=lambda kv: -sum(kv[1])):
         steady = sorted(v)[: max(1, len(v) * 3 // 4)]
         kern_mean_us = sum(v) / len(v) / 1e3
 lines.append('')
-for f in find('*kernel_stats.csv'):
+if full_durs:
+    lines += [f'Whole-config launch (1e7 samples, 8.72 GB algorithmic; separate trace): {len(full_durs)} launches, mean '
+              f'{sum(full_durs) / len(full_durs) / 1e3:.1f} us, min {min(full_durs) / 1e3:.1f} us = '
+              f'{8.72e9 / (sum(full_durs) / len(full_durs) * 1e-9) / 1e12:.2f} TB/s.', '']
+for f in [x for x in find('*kernel_stats.csv') if 'trace_full' not in str(x)]:
     lines += ['### rocprofv3 kernel_stats.csv (top rows, kernel names truncated)', '', '```']
     with open(f) as fd:
         for i, row in enumerate(csv.reader(fd)):
