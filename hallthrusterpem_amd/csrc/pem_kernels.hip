@@ -2106,11 +2106,12 @@ int pem_coupled_latent_f64_dev(size_t n, double torr2pa, double radius, const do
     PlumeIO io{(long long)n, torr2pa, radius, P_b, c0, c1, c2, c3, c4, c5, sigma_cex, nullptr, nullptr, nullptr, div_angle, T_c, invalid, nullptr,
                nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, basis, latent, rank, norm == PEM_NORM_LOG10 ? 1 : 0};
     CoupledIO cio{V_a, T_e, V_vac, Pstar, P_T, mdot_a, a_1, V_cc, nullptr, nullptr};
-    // two forms of the fused compression: 5 = profile norm staged in LDS + MFMA contraction, 4 = latents
-    // accumulated in the registers of the angle loop
-    static const int latent_mode = getenv("PEM_LATENT_MODE") ? atoi(getenv("PEM_LATENT_MODE")) : 5;
-    if (latent_mode == 4) return launch_r1<4, true, 4>(io, cio, static_cast<hipStream_t>(stream));
-    return launch_r1<4, true, 5>(io, cio, static_cast<hipStream_t>(stream));
+    // two forms of the fused compression: 4 = latents accumulated in the registers of the angle loop
+    // (default: 386 us per 1.25e6 samples), 5 = profile norm staged in LDS + MFMA contraction (403 us: the 91 log10 per
+    // sample bound both, the contraction was not the limiter; profiles/svd_probe_r02i.txt)
+    static const int latent_mode = getenv("PEM_LATENT_MODE") ? atoi(getenv("PEM_LATENT_MODE")) : 4;
+    if (latent_mode == 5) return launch_r1<4, true, 5>(io, cio, static_cast<hipStream_t>(stream));
+    return launch_r1<4, true, 4>(io, cio, static_cast<hipStream_t>(stream));
 }
 
 // ---- coupled, mixed precision: fp64 arithmetic, the 91-point profile stored as fp32 -----------------

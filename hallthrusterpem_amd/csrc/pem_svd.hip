@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "pem_common.h"
 #include "pem_math.h"
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(BLOCK) void svd_compress_kernel(long long n, int do
     }
 }
 
-// compress with the log10 norm, dof <= 96: no LDS tile at all.  A lane loads the values it will feed to the matrix pipe
+// compress for dof <= 96 (the 91-point profile): no LDS tile at all.  A lane loads the values it will feed to the matrix pipe
 // straight from `field` in the operand layout of v_mfma_f64_16x16x4_f64 -- lane (row, quad) takes field[sample row][4 step
 // + quad], steps 0..23: per instruction 16 rows x 32 contiguous bytes, every byte of the tile loaded exactly once -- takes
 // their log10 in registers (table version, the only LDS traffic left) and issues the 16 x 4 by 4 x 16 products against
@@ -233,22 +234,34 @@ __global__ __launch_bounds__(BLOCK) void svd_compress_kernel(long long n, int do
 // kernel at two waves per SIMD: this one is limited by its ~140 registers (three waves per SIMD), so one wave's loads are
 // in flight while the others take logs.
 constexpr int DIRECT_STEPS = 24;     // dof <= 96
-__global__ __launch_bounds__(BLOCK) void svd_compress_log10_direct_kernel(long long n, int dof, int r,
-                                                                         const double* __restrict__ field,
-                                                                         const double* __restrict__ basis,
-                                                                         double* __restrict__ latent) {
-    __shared__ __attribute__((aligned(16))) double logtab[pem::LOG_TABLE_DOUBLES];
-    pem::load_log_table(logtab, threadIdx.x, BLOCK);
+// BREG: the lane's 24 basis values live in registers for the whole launch (160 VGPRs, three waves per SIMD); otherwise they
+// are re-read from LDS per tile (conflict-free 8-byte reads) and the kernel is compiled for four waves per SIMD.
+template <int MODE, bool BREG>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BREG ? 3 : 4)))
+void svd_compress_direct_kernel(long long n, int dof, int r, double scale, const double* __restrict__ field,
+                                const double* __restrict__ basis, double* __restrict__ latent) {
+    __shared__ __attribute__((aligned(16))) double logtab[MODE == PEM_NORM_LOG10 ? pem::LOG_TABLE_DOUBLES : 2];
+    __shared__ double bas[BREG ? 1 : 4 * DIRECT_STEPS * 16];        // [k][column], zero padded
+    if constexpr (MODE == PEM_NORM_LOG10) pem::load_log_table(logtab, threadIdx.x, BLOCK);
+    if constexpr (!BREG) {
+        for (int i = threadIdx.x; i < 4 * DIRECT_STEPS * 16; i += BLOCK) {
+            const int k = i >> 4, c = i & 15;
+            bas[i] = (k < dof && c < r) ? basis[(size_t)k * r + c] : 0.0;
+        }
+    }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = lane & 15, quad = lane >> 4;
     // B[4 step + quad][column = row] = basis[k][row], zero past the rank and past dof
-    double b[DIRECT_STEPS];
+    double b[BREG ? DIRECT_STEPS : 1];
+    if constexpr (BREG) {
 #pragma unroll
-    for (int step = 0; step < DIRECT_STEPS; ++step) {
-        const int k = 4 * step + quad;
-        b[step] = (k < dof && row < r) ? basis[(size_t)k * r + row] : 0.0;
+        for (int step = 0; step < DIRECT_STEPS; ++step) {
+            const int k = 4 * step + quad;
+            b[step] = (k < dof && row < r) ? basis[(size_t)k * r + row] : 0.0;
+        }
     }
+    const double* bl = bas + quad * 16 + row;
     const long long ntiles = (n + 15) / 16;
     const long long stride = (long long)gridDim.x * WAVES;
     for (long long t = (long long)blockIdx.x * WAVES + wave; t < ntiles; t += stride) {
@@ -257,14 +270,15 @@ __global__ __launch_bounds__(BLOCK) void svd_compress_log10_direct_kernel(long l
         const double* src = field + smp * dof + quad;
         double a[DIRECT_STEPS];
 #pragma unroll
-        for (int step = 0; step < DIRECT_STEPS; ++step) a[step] = 4 * step + quad < dof ? src[4 * step] : 1.0;
+        for (int step = 0; step < DIRECT_STEPS; ++step) a[step] = 4 * step + quad < dof ? src[4 * step] : (MODE == PEM_NORM_LOG10 ? 1.0 : 0.0);
         f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int step = 0; step < DIRECT_STEPS; step += 2) {
-            // k >= dof: the value is 0 AFTER the norm (log10(1) = 0 exactly, and it meets a zero basis row)
-            const double l0 = pem::pem_log10_tab(a[step], logtab), l1 = pem::pem_log10_tab(a[step + 1], logtab);
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(l0, b[step], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(l1, b[step + 1], acc1, 0, 0, 0);
+            // k >= dof: the value is 0 AFTER the norm (log10(1) = 0 exactly), and it meets a zero basis row
+            const double l0 = norm_fwd<MODE>(scale, a[step], logtab), l1 = norm_fwd<MODE>(scale, a[step + 1], logtab);
+            const double b0 = BREG ? b[BREG ? step : 0] : bl[64 * step], b1 = BREG ? b[BREG ? step + 1 : 0] : bl[64 * step + 64];
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(l0, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(l1, b1, acc1, 0, 0, 0);
         }
         // lane (row, quad) holds D[sample quad + 4 i][column = row]
         if (row < r) {
@@ -397,11 +411,23 @@ int pem_svd_compress_f64_dev(size_t n, int dof, int rank, int norm, double norm_
         else if (norm == PEM_NORM_LINEAR) PEM_SVD_LAUNCH(ROWS_, UN_, RT_, PEM_NORM_LINEAR); \
         else PEM_SVD_LAUNCH(ROWS_, UN_, RT_, PEM_NORM_NONE);                                \
     } while (0)
-    if (norm == PEM_NORM_LOG10 && dof <= 4 * DIRECT_STEPS && !getenv("PEM_SVD_TILED")) {
+    if (dof <= 4 * DIRECT_STEPS && !getenv("PEM_SVD_TILED")) {
         size_t dblocks = ((n + 15) / 16 + WAVES - 1) / WAVES;
-        if (dblocks > 256 * 3) dblocks = 256 * 3;     // persistent: three workgroups (12 waves) per CU by registers
-        hipLaunchKernelGGL(svd_compress_log10_direct_kernel, dim3((unsigned)dblocks), dim3(BLOCK), 0, static_cast<hipStream_t>(stream),
-                           (long long)n, dof, rank, field, basis, latent);
+        static const bool breg = getenv("PEM_SVD_BREG") ? atoi(getenv("PEM_SVD_BREG")) != 0 : true;
+        const size_t per_cu = breg ? 3 : 4;           // persistent: workgroups (of four waves) resident per CU, by registers
+        if (dblocks > 256 * per_cu) dblocks = 256 * per_cu;
+        hipStream_t st = static_cast<hipStream_t>(stream);
+#define PEM_SVD_DIRECT(MODE_)                                                                                                   \
+    do {                                                                                                                        \
+        if (breg) hipLaunchKernelGGL((svd_compress_direct_kernel<MODE_, true>), dim3((unsigned)dblocks), dim3(BLOCK), 0, st,   \
+                                     (long long)n, dof, rank, norm_scale, field, basis, latent);                               \
+        else hipLaunchKernelGGL((svd_compress_direct_kernel<MODE_, false>), dim3((unsigned)dblocks), dim3(BLOCK), 0, st,       \
+                                (long long)n, dof, rank, norm_scale, field, basis, latent);                                    \
+    } while (0)
+        if (norm == PEM_NORM_LOG10) PEM_SVD_DIRECT(PEM_NORM_LOG10);
+        else if (norm == PEM_NORM_LINEAR) PEM_SVD_DIRECT(PEM_NORM_LINEAR);
+        else PEM_SVD_DIRECT(PEM_NORM_NONE);
+#undef PEM_SVD_DIRECT
         HIP_TRY(hipGetLastError());
         return PEM_OK;
     }
@@ -423,6 +449,9 @@ int pem_svd_reconstruct_f64_dev(size_t n, int dof, int rank, int norm, double no
     if (int rc = check_args("pem_svd_reconstruct", n, dof, rank, norm, latent, basis, field)) return rc;
     if (n == 0) return PEM_OK;
     if (int rc = pem::check_device()) return rc;
+    // (A direct form -- denorm and 8-byte stores straight from the MFMA result registers, no LDS tile -- was measured and
+    // dropped: 16 lanes write 128 contiguous bytes, but a 728-byte profile row puts those pieces across cache lines, and the
+    // kernel ran at 1.4-1.5 TB/s against 3.9 / 5.6 TB/s for the staged form below; profiles/svd_probe_r02k.txt.)
     const size_t lds = ((size_t)16 * (((dof + 15) / 16) * 16) + (size_t)WAVES * ((16 * dof + 3) & ~1)) * 8;
 #define PEM_SVD_RLAUNCH(MODE_)                                                                                       \
     do {                                                                                                             \

@@ -36,6 +36,9 @@ def test_single_gpu_line():
     assert r['bytes_per_eval'] == 872 and line['config']['samples_per_gpu'] == 131072
     assert abs(line['value'] - 131072 * 4 / (line['ms_per_step'] * 4e-3)) / line['value'] < 1e-9
     assert 'full_config' not in line['config'] and line['config']['gather'] == 'none'
+    # steps rotate over 8 batches (nothing is re-read from the Infinity Cache); the one-batch rate is reported beside, not as value
+    sb = line['config']['single_batch_rerun']
+    assert line['config']['batches_rotated'] == 8 and sb['value'] > 0 and 'NOT the headline' in sb['note']
     if r['traffic'] is not None:
         assert 'not measured in this run' in r['traffic_source']
 
