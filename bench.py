@@ -205,6 +205,7 @@ def main():
                          'collective per campaign; full = the 91-point profiles; none = no exchange')
     ap.add_argument('--chunks', type=int, default=4, help='pieces a shard is cut into at N>1 so that the all-gather of piece k '
                                                           'overlaps the evaluation of piece k+1')
+    ap.add_argument('--no-single-batch', action='store_true', help='skip the cache-assisted single-batch comparison run (profiling: every launch is then a rotating one)')
     ap.add_argument('--no-profile', action='store_true', help='reduced-QoI mode: never write j_ion (144 B/eval)')
     ap.add_argument('--mixed', action='store_true', help='fp64 arithmetic, fp32 storage of the profile (508 B/eval)')
     ap.add_argument('--fp32', action='store_true', help='add the fp32-arithmetic reduced-QoI kernel vs fp64 report (config 5)')
@@ -364,7 +365,7 @@ def main():
     frac_invalid = float(batch.invalid.float().mean().item())
     # the cache-assisted rate of ONE batch re-evaluated every step (what rounds 1 and 2a reported), for comparison only
     single = None
-    if nb > 1 and not multi:
+    if nb > 1 and not multi and not args.no_single_batch:
         for _ in range(5):
             batch.run()
         torch.cuda.synchronize()

@@ -178,7 +178,7 @@ def generate_data_on_device(n: int, seed: int = 0, description: str = 'test_set'
 
 # ------------------------------------------------------------------------------------------- Sobol' indices
 def sobol_indices(n_base: int, seed: int = 0, qois=QOI_NAMES, priors=None, fixed: dict | None = None,
-                  batch_size: int = 1 << 20, device=None, group=None, precision: str = 'fp64'):
+                  batch_size: int = 1 << 20, device=None, group=None, precision: str = 'fp64', fused: bool | None = None):
     """First-order and total Sobol' indices of scalar QoIs by the Saltelli design: N (d + 2) evaluations for the
     d non-constant inputs (matrices A, B and A with column i from B), `compute_s2=False` as sobol.py:113 asks.
 
@@ -188,11 +188,14 @@ def sobol_indices(n_base: int, seed: int = 0, qois=QOI_NAMES, priors=None, fixed
     With a torch.distributed `group` every rank evaluates its shard of the N base samples and the sums are
     all-reduced (O(d * n_qoi) doubles).  Returns {'S1': {qoi: [d]}, 'ST': ..., 'inputs': names}.
 
+    fused (default True): the whole shard in ONE launch that keeps design rows, QoIs and estimator terms on chip and
+    accumulates the sums in fp64 (`pem_saltelli_f64_dev` / `pem_saltelli_f32_dev`, csrc/pem_saltelli.hip); the result then
+    also carries `non_physical` / `invalid` counts (the thruster filter of thruster.py:490-493 and plume.py:105 over all
+    evaluations).  fused=False (fp64 only) is the block-by-block driver: d + 2 fused sample+evaluate launches and as many
+    partial-sum launches per batch.
     precision='fp32' (BASELINE configs[4]: "fp64 -> fp32 mixed with tolerance check"): the SAME design -- the fp64
-    counter-based rows, rounded to float -- through the fp32-arithmetic model, the whole shard in ONE launch that keeps
-    design rows, QoIs and estimator terms in registers (`pem_saltelli_f32_dev`, csrc/pem_fp32.hip) and accumulates the
-    sums in fp64.  The result also carries `non_physical` / `invalid` counts (the thruster filter of thruster.py:490-493
-    and plume.py:105 over all evaluations).  fp32.compare_with_fp64 is the per-QoI tolerance report of the model."""
+    counter-based rows, rounded to float -- through the fp32-arithmetic model.  fp32.compare_with_fp64 is the per-QoI
+    tolerance report of that model."""
     import torch
     import torch.distributed as dist
     pri = dict(sampling.PEM_V0_PRIORS if priors is None else priors)
@@ -213,12 +216,15 @@ def sobol_indices(n_base: int, seed: int = 0, qois=QOI_NAMES, priors=None, fixed
         raise ValueError(f'sobol_indices handles the scalar QoIs V_cc, div_angle, T_c; got {qois}')
     if precision not in ('fp64', 'fp32'):
         raise ValueError("precision must be 'fp64' or 'fp32'")
+    fused = True if fused is None else bool(fused)
+    if precision == 'fp32' and not fused:
+        raise ValueError('the fp32 model exists in the fused launch only')
     counts = None
-    if precision == 'fp32':
+    if fused:
         from .fp32 import saltelli_sums
         counts = torch.zeros(2, dtype=torch.int64, device=dev)
         if hi > lo:
-            sums, counts = saltelli_sums(design, varied, hi - lo, first_index=lo, device=dev)
+            sums, counts = saltelli_sums(design, varied, hi - lo, first_index=lo, device=dev, precision=precision)
             sums = sums[:, rows]
             acc[0], acc[1], acc[2] = sums[0], sums[1], 2 * (hi - lo)
             acc[3:3 + nd], acc[3 + nd:] = sums[2::2], sums[3::2]
@@ -275,7 +281,7 @@ def sobol_indices(n_base: int, seed: int = 0, qois=QOI_NAMES, priors=None, fixed
     names = [design.names[d] for d in varied]
     res = {'S1': {q: S1[:, i] for i, q in enumerate(qois)}, 'ST': {q: ST[:, i] for i, q in enumerate(qois)},
            'inputs': names, 'mean': {q: mean[i] for i, q in enumerate(qois)}, 'var': {q: var[i] for i, q in enumerate(qois)},
-           'evaluations': int(n_base) * (nd + 2), 'precision': precision}
+           'evaluations': int(n_base) * (nd + 2), 'precision': precision, 'fused': fused}
     if counts is not None:
         res['non_physical'], res['invalid'] = int(counts[0]), int(counts[1])
     return res

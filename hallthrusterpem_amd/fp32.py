@@ -92,9 +92,11 @@ def compare_with_fp64(n: int, fill=None, seed: int = 2) -> dict:
     return report
 
 
-def saltelli_sums(design, varied, n_base: int, first_index: int = 0, radius: float = 1.0, n_blocks: int = 512, device=None, stream=None):
-    """One launch of the fused Saltelli design (`pem_saltelli_f32_dev`): base samples first_index .. first_index+n_base-1
-    of `design` (rows A: its stream, B: stream + 1), `varied` = indices of the inputs that get an AB block.
+def saltelli_sums(design, varied, n_base: int, first_index: int = 0, radius: float = 1.0, n_blocks: int = 512, device=None, stream=None,
+                  precision: str = 'fp32'):
+    """One launch of the fused Saltelli design (`pem_saltelli_f32_dev` / `pem_saltelli_f64_dev`, csrc/pem_saltelli.hip): base
+    samples first_index .. first_index+n_base-1 of `design` (rows A: its stream, B: stream + 1), `varied` = indices of the
+    inputs that get an AB block; `precision` picks the model (fp32 arithmetic on the design rounded to float, or fp64).
     Returns (sums [2 + 2 nv][3] float64 CUDA tensor, flags [2] int64: non-physical thruster results, invalid plume samples)."""
     import torch
     dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
@@ -105,8 +107,8 @@ def saltelli_sums(design, varied, n_base: int, first_index: int = 0, radius: flo
     flags = torch.empty((n_blocks, 2), dtype=torch.int64, device=dev)
     ptr = lambda arr: C.c_void_p(arr.ctypes.data)                                               # noqa: E731
     with torch.cuda.device(dev):
-        _lib.check(_lib.load().pem_saltelli_f32_dev(int(n_base), int(first_index), design.seed, design.stream, ptr(design.kind), ptr(design.a),
-                                                    ptr(design.b), nv, ptr(varied), constants.TORR_2_PA, float(radius),
-                                                    C.c_void_p(partial.data_ptr()), C.c_void_p(flags.data_ptr()), int(n_blocks),
-                                                    C.c_void_p(s.cuda_stream)))
+        fn = _lib.load().pem_saltelli_f32_dev if precision == 'fp32' else _lib.load().pem_saltelli_f64_dev
+        _lib.check(fn(int(n_base), int(first_index), design.seed, design.stream, ptr(design.kind), ptr(design.a), ptr(design.b), nv,
+                      ptr(varied), constants.TORR_2_PA, float(radius), C.c_void_p(partial.data_ptr()), C.c_void_p(flags.data_ptr()),
+                      int(n_blocks), C.c_void_p(s.cuda_stream)))
     return partial.sum(dim=0), flags.sum(dim=0)

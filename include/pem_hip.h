@@ -281,6 +281,11 @@ int pem_coupled_f32_dev(size_t n, float torr2pa, float radius, const float* x, s
 int pem_saltelli_f32_dev(size_t n_base, uint64_t first_index, uint64_t seed, uint32_t stream_id, const int32_t* kind,
                          const double* a, const double* b, int n_varied, const int32_t* varied, float torr2pa,
                          float radius, double* partial, uint64_t* flags, int n_blocks, pem_stream_t stream);
+/* The same launch around the fp64 model (lane per sample; the scalar stages and tables of the coupled kernel, bit-identical
+ * to pem_coupled_f64_dev's reduced-QoI results for samples inside the table range), on the design itself, not rounded.  */
+int pem_saltelli_f64_dev(size_t n_base, uint64_t first_index, uint64_t seed, uint32_t stream_id, const int32_t* kind,
+                         const double* a, const double* b, int n_varied, const int32_t* varied, double torr2pa,
+                         double radius, double* partial, uint64_t* flags, int n_blocks, pem_stream_t stream);
 
 #ifdef __cplusplus
 }

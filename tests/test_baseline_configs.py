@@ -102,7 +102,8 @@ def test_config_2e7_saltelli_design():
     oc.set_threads(16)
     fixed = {'P_b': 1e-5, 'V_a': 300.0, 'mdot_a': 5e-6}                      # operating point held, as sobol.py:104
     n_base = 1_428_572                                                       # x (12 + 2) = 20,000,008 evaluations
-    full = drivers.sobol_indices(n_base, seed=1, fixed=fixed, batch_size=1 << 21)
+    full = drivers.sobol_indices(n_base, seed=1, fixed=fixed)                 # one fused launch, fp64 model
+    assert full['fused'] and full['non_physical'] == 0 and full['invalid'] == 0
     assert full['evaluations'] == n_base * 14 >= 20_000_000 and len(full['inputs']) == 12
     for q in ('V_cc', 'div_angle', 'T_c'):
         assert torch.isfinite(full['S1'][q]).all() and torch.isfinite(full['ST'][q]).all()
@@ -125,7 +126,8 @@ def test_config_2e7_saltelli_design():
 
     # the estimator against the numpy restatement (numpy Philox design, oracle as the model) on a 1.12e6-evaluation sub-design
     N = 80_000
-    got = drivers.sobol_indices(N, seed=1, fixed=fixed, batch_size=1 << 16)
+    got = drivers.sobol_indices(N, seed=1, fixed=fixed, batch_size=1 << 16, fused=False)     # the block-by-block driver
+    fused_sub = drivers.sobol_indices(N, seed=1, fixed=fixed)
     kind = [pri[k].kind for k in COUPLED_INPUTS]
     lo, hi = [pri[k].a for k in COUPLED_INPUTS], [pri[k].b for k in COUPLED_INPUTS]
 
@@ -141,6 +143,7 @@ def test_config_2e7_saltelli_design():
         for i, q in enumerate(('V_cc', 'div_angle', 'T_c')):
             assert float(got['S1'][q][j]) == pytest.approx(s1[i], abs=2e-9)
             assert float(got['ST'][q][j]) == pytest.approx(st[i], abs=2e-9)
+            assert float(fused_sub['S1'][q][j]) == pytest.approx(s1[i], abs=2e-9) and float(fused_sub['ST'][q][j]) == pytest.approx(st[i], abs=2e-9)
             # and the full design agrees with its own first 80 000 base samples to Monte-Carlo accuracy
             assert float(full['ST'][q][j]) == pytest.approx(st[i], abs=0.02)
 

@@ -93,11 +93,40 @@ def test_fused_saltelli_launch_equals_the_block_by_block_fp32_pipeline():
     assert 0.4 * 5000 * 14 < int(flags[0]) < 0.6 * 5000 * 14
 
 
+def test_fused_fp64_launch_equals_the_block_by_block_fp64_driver():
+    """pem_saltelli_f64_dev (lane-per-sample fp64 model inside the fused launch) against drivers.sobol_indices(fused=False)
+    (d + 2 launches of the tile kernel's reduced-QoI mode + partial-sum kernels): the same design, the same QoIs -- bit for
+    bit inside the table range -- so the estimator sums agree to the rounding of their different summation orders."""
+    from hallthrusterpem_amd import drivers
+    fixed = {'P_b': 1e-5, 'V_a': 300.0, 'mdot_a': 5e-6}
+    for N, bs in ((50_000, 1 << 14), (777, 256)):
+        a = drivers.sobol_indices(N, seed=21, fixed=fixed, batch_size=bs, fused=False)
+        b = drivers.sobol_indices(N, seed=21, fixed=fixed)
+        assert b['fused'] and not a['fused'] and b['non_physical'] == 0 and b['invalid'] == 0
+        for q in ('V_cc', 'div_angle', 'T_c'):
+            assert float(b['mean'][q]) == pytest.approx(float(a['mean'][q]), rel=1e-13)
+            assert float(b['var'][q]) == pytest.approx(float(a['var'][q]), rel=1e-11)
+            for key in ('S1', 'ST'):
+                assert float((a[key][q] - b[key][q]).abs().max()) < 1e-11, (N, q, key)
+    # outside the table range (beams narrower than 0.03 rad, negative amplitudes) the fused model sums the 91 terms
+    # literally where the tile kernel runs its recurrence: equal to 1e-10, not bit for bit
+    from hallthrusterpem_amd import sampling
+    pri = dict(sampling.PEM_V0_PRIORS)
+    pri['c3'] = sampling.Prior(sampling.UNIFORM, 0.005, 0.3, 'test: narrow beams')
+    pri['c0'] = sampling.Prior(sampling.UNIFORM, -0.2, 1.2, 'test: amplitudes of either sign')
+    a = drivers.sobol_indices(20_000, seed=3, priors=pri, fixed=fixed, batch_size=1 << 13, fused=False)
+    b = drivers.sobol_indices(20_000, seed=3, priors=pri, fixed=fixed)
+    assert b['invalid'] > 0
+    for q in ('V_cc', 'T_c'):
+        assert float(b['var'][q]) == pytest.approx(float(a['var'][q]), rel=1e-9)
+        assert float((a['ST'][q] - b['ST'][q]).abs().max()) < 1e-8
+
+
 def test_sobol_indices_fp32_against_fp64_on_the_same_design():
     from hallthrusterpem_amd import drivers
     fixed = {'P_b': 1e-5, 'V_a': 300.0, 'mdot_a': 5e-6}
     N = 200_000
-    a = drivers.sobol_indices(N, seed=4, fixed=fixed, batch_size=1 << 18)
+    a = drivers.sobol_indices(N, seed=4, fixed=fixed)
     b = drivers.sobol_indices(N, seed=4, fixed=fixed, precision='fp32')
     assert a['inputs'] == b['inputs'] and b['evaluations'] == N * 14 and b['non_physical'] == 0 and b['invalid'] == 0
     worst = 0.0

@@ -2,7 +2,7 @@
 """Differential fuzzing of the device path against the CPU oracle (test infrastructure) on inputs far outside the
 priors: signs, zeros, huge / tiny magnitudes, NaN / inf, beams around every table boundary.  For each seed the coupled
 evaluation runs in full, reduced and mixed mode, fused with the likelihood and with the SVD compression (against their
-two-launch pipelines), and the plume alone with one, three and five radii.
+two-launch pipelines), and the plume alone with one, two, three and five radii.
 
 NaN / inf / invalid patterns must agree exactly.  Finite values are held to the north_star's 1e-10 relative, and where a
 result is a cancelling sum (negative amplitudes or densities, c0 outside [0, 1] -- none of which the priors reach) to
@@ -195,10 +195,10 @@ def main():
             scale = np.nansum(np.abs(np.log10(np.abs(ref.j_ion.cpu().numpy()))), axis=1, keepdims=True)   # sum_k |log10 j_k|
         fin = np.isfinite(want_z) & np.isfinite(scale)
         note('fused.latent', np.max((np.abs(got_z - want_z) / np.maximum(scale, 1.0))[fin], initial=0.0))
-        # plume alone: one radius (fast path), three and five radii (wave-per-sample kernel)
+        # plume alone: one radius (fast path), two / three / five radii (few-radii recurrence kernel, even and odd R)
         p = dict(pin)
         p['I_B0'], p['T'] = full['I_B0'], full['T']
-        for radii in ((1.0,), (0.5, 1.0, 2.5), (0.5, 0.8, 1.0, 1.7, 2.5)):
+        for radii in ((1.0,), (0.7, 1.3), (0.5, 1.0, 2.5), (0.5, 0.8, 1.0, 1.7, 2.5)):     # R = 2: the 16-byte-store form of the few-radii kernel
             with np.errstate(all='ignore'):
                 w = oc.plume(p['P_b'], p['c0'], p['c1'], p['c2'], p['c3'], p['c4'], p['c5'], p['sigma_cex'], p['I_B0'], k, T=p['T'], radii=radii)
                 tR = oc.plume_terms(*[pin[q] for q in ('P_b', 'c0', 'c1', 'c2', 'c3', 'c4', 'c5', 'sigma_cex')], p['I_B0'], k, radii=radii)
