@@ -990,209 +990,64 @@ __global__ __launch_bounds__(BLOCK) void plume_radii_kernel(PlumeIO io, RadiiArg
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// sweep_radius arrays with FEW radii, 2 <= R <= RADII_SMALL: the shape of tests/test_plume.py:31-style calls with a
-// handful of probe radii.  plume_radii_kernel above spends most of its instructions per SAMPLE on work that only R of
-// the 64 lanes take part in (the per-radius amplitudes and the divergence angle, lane = radius) -- 1.2-2.0 TB/s of output
-// for R = 2..5.  Here that work is done for a whole tile at once:
-//   prelude    lane = sample: the sample's parameters, then a loop over the R radii: decay, j_cex and the two beam
-//              amplitudes of every (sample, radius) pair go to LDS
-//   per sample the wave computes the two Gaussians (lane = angle; exp_nonpos instead of the library exp), their four
-//              Simpson functionals (one transposing wave reduction) and streams the (91, R) block, 16 bytes per lane
-//   postlude   lane = (sample, radius) pair: cos_div, arccos, T_c for the whole tile, coalesced stores
-// Samples whose amplitudes are of opposite sign or near the overflow threshold take the literal angle-by-angle sums for
-// the divergence integrals, exactly as in plume_radii_kernel (rare).
-// ---------------------------------------------------------------------------------------------
 constexpr int RADII_SMALL = 8;
-constexpr int RS_TS = 64;            // samples per wave tile
 struct RadiiSmallArg {
     double r[RADII_SMALL];
 };
 
-// sum four per-lane values over the wave; lane l ends up with the total of v[2 (l & 1) + ((l >> 1) & 1)]
-__device__ __forceinline__ double wave_sum4(const double (&v)[4], int lane) {
-    const bool b0 = lane & 1, b1 = lane & 2;
-    double w2[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const double send = b0 ? v[k] : v[k + 2], keep = b0 ? v[k + 2] : v[k];
-        w2[k] = keep + __shfl_xor(send, 1);
-    }
-    const double send = b1 ? w2[0] : w2[1], keep = b1 ? w2[1] : w2[0];
-    double w = keep + __shfl_xor(send, 2);
-#pragma unroll
-    for (int m = 4; m < WAVE; m <<= 1) w += __shfl_xor(w, m);
-    return w;
-}
-
-__global__ __launch_bounds__(BLOCK) void plume_radii_small_kernel(PlumeIO io, RadiiSmallArg radii_arg, int R, int ts) {
-#pragma clang fp contract(off)
-    // per wave: e1[96] e2[96] | S[RS_TS][4] | PB[RS_TS * R][3] {b1, b2, j_cex}
-    __shared__ double lds_all[BLOCK / WAVE][2 * 96 + RS_TS * 4 + RS_TS * RADII_SMALL * 3];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    double* e1 = lds_all[wave];
-    double* e2 = e1 + 96;
-    double* S = e2 + 96;
-    double* PB = S + RS_TS * 4;
-    const long long nwaves = (long long)gridDim.x * (BLOCK / WAVE);
-    const bool have_T = io.T != nullptr;
-    const long long ntiles = (io.n + ts - 1) / ts;
-    const int slot4 = 2 * (lane & 1) + ((lane >> 1) & 1);
-    const int blk = NANG * R;                              // doubles per sample block
-    for (long long t = blockIdx.x * (BLOCK / WAVE) + wave; t < ntiles; t += nwaves) {
-        const int in_tile = (int)(io.n - t * ts < ts ? io.n - t * ts : ts);
-        const long long gl = lane < in_tile ? t * ts + lane : io.n - 1;    // idle lanes repeat the last sample
-        const double c0_l = io.c0[gl], c1_l = io.c1[gl];
-        const PlumeSetup ps_l = plume_setup(io.P_b[gl], c1_l, io.c2[gl], io.c3[gl], io.c4[gl], io.c5[gl], io.torr2pa);
-        const double a1_l = ps_l.a1, a2_l = ps_l.a2, sigma_l = io.sigma[gl], IB0_l = io.I_B0[gl];
-        const double A1_l = (1.0 - c0_l) / normaliser(a1_l, 1.0 / (a1_l * a1_l), PEM_DPOLY);
-        const double A2_l = c0_l / normaliser(a2_l, 1.0 / (a2_l * a2_l), PEM_DPOLY);
-        unsigned literal_l = 0;                             // bit r: (sample, radius r) sums its integrals angle by angle
-        for (int r = 0; r < R; ++r) {
-            const double rad = radii_arg.r[r];
-            const double decay = exp(-rad * ps_l.n_neutral * sigma_l);
-            const double j_cex = IB0_l * (1.0 - decay) / (2.0 * PEM_PI * (rad * rad));
-            const double base = IB0_l * decay / (rad * rad);
-            const double b1 = base * A1_l, b2 = base * A2_l;
-            double* pb = PB + (lane * R + r) * 3;
-            pb[0] = b1;
-            pb[1] = b2;
-            pb[2] = j_cex;
-            if (!(fabs(b1) + fabs(b2) < 1e300) || ((b1 < 0.0) != (b2 < 0.0) && b1 != 0.0 && b2 != 0.0)) literal_l |= 1u << r;
-        }
-        wave_lds_sync();
-        for (int smp = 0; smp < in_tile; ++smp) {
-            const long long g = t * ts + smp;
-            const double a1 = __shfl(a1_l, smp), a2 = __shfl(a2_l, smp);
-            const unsigned literal = (unsigned)__shfl((int)literal_l, smp);
-            // the two Gaussians of plume.py:99-100 and their four Simpson functionals
-            double part[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int k = lane; k < NANG; k += WAVE) {
-                const double alpha = k == NANG - 1 ? HALF_PI : (double)k * GRID_H;
-                const double t1 = alpha / a1, t2 = alpha / a2;
-                const double g1 = exp_nonpos(-(t1 * t1)), g2 = exp_nonpos(-(t2 * t2));
-                e1[k] = g1;
-                e2[k] = g2;
-                part[0] = __builtin_fma(PEM_SIMPSON_CDEN[k], g1, part[0]);
-                part[1] = __builtin_fma(PEM_SIMPSON_CNUM[k], g1, part[1]);
-                part[2] = __builtin_fma(PEM_SIMPSON_CDEN[k], g2, part[2]);
-                part[3] = __builtin_fma(PEM_SIMPSON_CNUM[k], g2, part[3]);
-            }
-            const double tot = wave_sum4(part, lane);
-            if (lane < 4) S[smp * 4 + slot4] = tot;        // S[smp] = {s1d, s1n, s2d, s2n}
-            wave_lds_sync();
-            if (literal) {   // rare, wave-uniform: the reference's own summation order for the flagged radii
-                if (lane < R && ((literal >> lane) & 1)) {
-                    const double* pb = PB + (smp * R + lane) * 3;
-                    double den = 0.0, num = 0.0;
-                    for (int k = 0; k < NANG; ++k) {
-                        const double f = pb[0] * e1[k] + pb[1] * e2[k];
-                        den = __builtin_fma(PEM_SIMPSON_CDEN[k], f, den);
-                        num = __builtin_fma(PEM_SIMPSON_CNUM[k], f, num);
-                    }
-                    double cos_div = num / den;
-                    if (cos_div == __builtin_inf()) cos_div = __builtin_nan("");
-                    io.div[(size_t)g * R + lane] = acos(cos_div);
-                    if (have_T) io.Tc[(size_t)g * R + lane] = io.T[g] * cos_div;
-                }
-            }
-            // the (91, R) block, contiguous: element idx = k R + r.  Lanes take PAIRS of elements (16-byte stores); a block
-            // that starts at an odd double (91 R odd and g odd) is shifted by one element, which lane 0 stores on its own.
-            double* dst = io.j_ion + (size_t)g * blk;
-            const double* pbs = PB + smp * R * 3;
-            const int odd = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);
-            bool bad = a1 <= 0.0;
-            auto value = [&](int idx) {
-                const int k = idx / R, r = idx - k * R;
-                const double* pb = pbs + r * 3;
-                return (pb[0] * e1[k] + pb[1] * e2[k]) + pb[2];
-            };
-            if (odd && lane == 0) {
-                const double ji = value(0);
-                bad |= ji <= 0.0;
-                dst[0] = ji;
-            }
-            for (int idx = odd + 2 * lane; idx < blk; idx += 2 * WAVE) {
-                const double j0 = value(idx);
-                bad |= j0 <= 0.0;
-                if (idx + 1 < blk) {
-                    const double j1 = value(idx + 1);
-                    bad |= j1 <= 0.0;
-                    f64x2 v;
-                    v.x = j0;
-                    v.y = j1;
-                    __builtin_nontemporal_store(v, reinterpret_cast<f64x2*>(dst + idx));
-                } else {
-                    dst[idx] = j0;
-                }
-            }
-            const bool invalid = __ballot(bad) != 0;
-            if (invalid)   // plume.py:106: the whole block becomes 1e-20 (rare: a second pass over it)
-                for (int idx = lane; idx < blk; idx += WAVE) dst[idx] = 1e-20;
-            if (io.invalid && lane == 0) io.invalid[g] = (uint8_t)invalid;
-            wave_lds_sync();   // e1 / e2 are rewritten for the next sample
-        }
-        // postlude: the divergence angle of every (sample, radius) pair of the tile (linear in the amplitudes)
-        const int pairs = in_tile * R;
-        for (int idx = lane; idx < pairs; idx += WAVE) {
-            const int smp = idx / R, r = idx - smp * R;
-            const unsigned literal = (unsigned)__shfl((int)literal_l, smp);
-            if ((literal >> r) & 1) continue;
-            const double* pb = PB + idx * 3;
-            const double* sv = S + smp * 4;
-            const double num = pb[0] * sv[1] + pb[1] * sv[3], den = pb[0] * sv[0] + pb[1] * sv[2];
-            double cos_div = num / den;
-            if (cos_div == __builtin_inf()) cos_div = __builtin_nan("");
-            const long long g = t * ts + smp;
-            io.div[(size_t)g * R + r] = acos(cos_div);
-            if (have_T) io.Tc[(size_t)g * R + r] = io.T[g] * cos_div;
-        }
-        wave_lds_sync();   // PB / S are rewritten by the next tile
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
-// FEW radii by recurrence: the R = 1 fast path generalised (2 <= R <= RADII_SMALL).  The two kernels above are bound by
-// LATENCY, not by issue or HBM: a wave has one sample in flight, and every sample is a chain Gaussians -> LDS -> wave
-// reduction -> LDS -> block stream (5.4k cycles per sample measured at R = 2 where the instruction count says 1.3k:
-// profiles/radii_probe_r02e.txt).  Here a wave works on 8 samples at a time as plume_r1_kernel does: lane (s, c) walks
+// FEW radii by recurrence: the R = 1 fast path generalised (2 <= R <= RADII_SMALL).  The wave-per-sample kernel above is
+// bound by LATENCY, not by issue or HBM: a wave has one sample in flight, and every sample is a chain Gaussians -> LDS ->
+// wave reduction -> LDS -> block stream (5.4k cycles per sample measured at R = 2 where the instruction count says 1.3k;
+// moving the per-radius work out of that chain gained 10-19 %: profiles/radii_probe_r02.txt).  Here a wave works on 8 samples at a time as plume_r1_kernel does: lane (s, c) walks
 // angles k = 12 c .. 12 c + 11 of sample s, advancing the two Gaussians by the two-term recurrence (4 multiplies per
 // angle) from chunk starts that come from the same recurrence at stride 12; per angle it forms the R values
-// b1[r] e1 + b2[r] e2 + j_cex[r] from amplitudes it holds in registers and stores them -- R consecutive doubles of j_ion --
-// straight from the loop.  The Simpson functionals of the two Gaussians ride along (4 FMAs per angle) and are folded over
+// b1[r] e1 + b2[r] e2 + j_cex[r] from amplitudes it holds in registers and puts them -- R consecutive doubles -- into an LDS
+// tile laid out as j_ion is, which leaves as 1-KiB-per-instruction 16-byte stores when the round is done.  The Simpson functionals of the two Gaussians ride along (4 FMAs per angle) and are folded over
 // the 8 chunk lanes; cos_div / arccos / T_c of all (sample, radius) pairs of the 64-sample tile follow, one lane per pair.
 // "Equal to the reference" in the deep tail is kept as in the R = 1 path: a chunk with a value below 1e-290 (or <= 0, or
 // a non-finite amplitude) is re-evaluated literally with direct exp(); amplitudes of opposite sign or near overflow send
 // the pair's divergence integrals through the literal angle-by-angle sum.
-// LDS (doubles): shared: simpson[96][2] | dpoly[384];  per wave: params[8][64] | sums[64][4] | PB[64][R][3]
+// LDS (doubles): shared: simpson[96][2] | dpoly[384];  per wave: params[8][64] | PB[64][R][3] | tile[8][91][R]
 // ---------------------------------------------------------------------------------------------
 constexpr int RF_L = 8, RF_S = WAVE / RF_L, RF_CH = 12;
 static_assert(RF_L * RF_CH >= NANG && RF_L * RF_CH <= NSIMP, "8 chunks of 12 angles cover the 91-point grid inside the padded table");
+// per wave: params[8][64] | PB[64][R][3] | tile[8][91][R] + 2; the workgroup has as many waves as fit 160 KB beside the tables
+template <int R>
+constexpr int rfew_wave_doubles() { return 8 * WAVE + 3 * WAVE * R + RF_S * NANG * R + 2; }
+template <int R>
+constexpr int rfew_waves() { return R <= 4 ? 4 : (R <= 6 ? 3 : 2); }
 
 template <int R>   // the number of radii is a compile-time constant: amplitudes and the values of two angles live in registers
-__global__ __launch_bounds__(WAVE * WPB) void plume_rfew_kernel(PlumeIO io, RadiiSmallArg radii_arg) {
+__global__ __launch_bounds__(WAVE * rfew_waves<R>()) void plume_rfew_kernel(PlumeIO io, RadiiSmallArg radii_arg) {
     constexpr int RM = R;
+    // A round's 8 x 91 x R values go to an LDS tile in final order and leave as 1-KiB-per-instruction 16-byte stores, as in
+    // the R = 1 path.  (Stored straight from the angle loop instead -- 16 bytes per lane, 64 separate pieces per instruction
+    // -- the kernel ran at 2.1-2.4 TB/s; staged 3.7-4.7: profiles/radii_probe_r02.txt.)  The tile grows with R, so the
+    // workgroup shrinks: 4 waves up to R = 4, 3 up to 6, 2 for 7 and 8.
+    constexpr int NW = rfew_waves<R>();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* lds = reinterpret_cast<double*>(smem_raw);
     double2* tab_simpson = reinterpret_cast<double2*>(lds);
     double* tab_poly = lds + 2 * NSIMP;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int per_wave = 8 * WAVE + 4 * WAVE + 3 * WAVE * R;
+    constexpr int per_wave = rfew_wave_doubles<R>();
     double* params = lds + TABLE_DOUBLES + wave * per_wave;     // rows: a1 a2 | r0 G E (beam 1) | r0 G E (beam 2)
-    double* sums = params + 8 * WAVE;                           // [64][4] {s1d, s1n, s2d, s2n}
-    double* PB = sums + 4 * WAVE;                               // [64][R][3] {b1, b2, j_cex}
-    for (int i = tid; i < NSIMP; i += WAVE * WPB)
+    // a sample's rows 2..5 are free once its round has read them: they then carry its {s1d, s1n, s2d, s2n}
+    double* PB = params + 8 * WAVE;                             // [64][R][3] {b1, b2, j_cex}
+    double* tile = PB + 3 * WAVE * R;                           // [8][91][R] + 2
+    for (int i = tid; i < NSIMP; i += WAVE * NW)
         tab_simpson[i] = i < NANG ? make_double2(PEM_SIMPSON_CDEN[i], PEM_SIMPSON_CNUM[i]) : make_double2(0.0, 0.0);
-    for (int i = tid; i < PEM_NDI * PEM_NDC; i += WAVE * WPB) tab_poly[i] = PEM_DPOLY[i];
+    for (int i = tid; i < PEM_NDI * PEM_NDC; i += WAVE * NW) tab_poly[i] = PEM_DPOLY[i];
     __syncthreads();
 
     const int s = lane % RF_S, c = lane / RF_S, k0 = c * RF_CH;
     const double2* my_w = tab_simpson + k0;
     const bool have_T = io.T != nullptr;
     const long long ntiles = (io.n + WAVE - 1) / WAVE;
-    const long long nwaves = (long long)gridDim.x * WPB;
+    const long long nwaves = (long long)gridDim.x * NW;
     const size_t blk = (size_t)NANG * R;
-    for (long long t = (long long)blockIdx.x * WPB + wave; t < ntiles; t += nwaves) {
+    for (long long t = (long long)blockIdx.x * NW + wave; t < ntiles; t += nwaves) {
         const int in_tile = (int)(io.n - t * WAVE < WAVE ? io.n - t * WAVE : WAVE);
         const long long gl = lane < in_tile ? t * WAVE + lane : io.n - 1;     // idle lanes repeat the last sample
         // ------------------------------ prelude: one lane per sample ------------------------------
@@ -1233,8 +1088,6 @@ __global__ __launch_bounds__(WAVE * WPB) void plume_rfew_kernel(PlumeIO io, Radi
         // ------------------------------ rounds: 8 samples, 8 chunk lanes each ------------------------------
         for (int round = 0; round < RF_L; ++round) {
             const int smp = round * RF_S + s;
-            const long long g = t * WAVE + smp;
-            const bool exists = smp < in_tile;
             const double r01 = params[2 * WAVE + smp], G1 = params[3 * WAVE + smp], E1 = params[4 * WAVE + smp];
             const double r02 = params[5 * WAVE + smp], G2 = params[6 * WAVE + smp], E2 = params[7 * WAVE + smp];
             double b1[RM], b2[RM], jc[RM];
@@ -1264,8 +1117,8 @@ __global__ __launch_bounds__(WAVE * WPB) void plume_rfew_kernel(PlumeIO io, Radi
             }
             const double q1 = r01 * r01, q2 = r02 * r02;
             double part[4] = {0.0, 0.0, 0.0, 0.0}, lo = __builtin_inf();
-            double* dst = io.j_ion + (size_t)g * blk + (size_t)k0 * R;
-            // The chunk's values are one run of 12 R consecutive doubles of j_ion.  Two angles = 2 R doubles per iteration,
+            double* dst = tile + (size_t)s * blk + (size_t)k0 * R;
+            // The chunk's values are one run of 12 R consecutive doubles of the tile (laid out as j_ion is).  Two angles = 2 R doubles per iteration,
             // stored as R 16-byte pieces.  For an odd R the run of an odd sample starts at an odd double (the start is
             // (g 91 + 12 c) R doubles into a 16-byte aligned array): such a lane stores its first double on its own, then
             // pieces shifted by one element (the last element of an iteration is carried into the next), and the last
@@ -1293,7 +1146,7 @@ __global__ __launch_bounds__(WAVE * WPB) void plume_rfew_kernel(PlumeIO io, Radi
                 if (k0 + jj + 1 < NANG) {                  // both angles exist (all but the last iterations of the last chunk)
 #pragma unroll
                     for (int i = 0; i < 2 * RM; ++i) lo = fmin(lo, ev[i]);
-                    if (exists) {
+                    {
                         if constexpr ((R & 1) == 0) {
 #pragma unroll
                             for (int q = 0; q < RM; ++q) *reinterpret_cast<f64x2*>(d + 2 * q) = f64x2{ev[2 * q], ev[2 * q + 1]};
@@ -1314,12 +1167,12 @@ __global__ __launch_bounds__(WAVE * WPB) void plume_rfew_kernel(PlumeIO io, Radi
                     if (k0 + jj < NANG) {
 #pragma unroll
                         for (int r = 0; r < RM; ++r) lo = fmin(lo, ev[r]);
-                        if (exists) {
+                        {
                             if ((R & 1) && mis && jj > 0) d[-1] = carry;           // the carried double of the iteration before
 #pragma unroll
                             for (int r = 0; r < RM; ++r) d[r] = ev[r];
                         }
-                    } else if ((R & 1) && mis && exists && jj > 0 && k0 + jj - 1 < NANG) {
+                    } else if ((R & 1) && mis && jj > 0 && k0 + jj - 1 < NANG) {
                         d[-1] = carry;
                     }
                     carry = 0.0;
@@ -1344,7 +1197,7 @@ __global__ __launch_bounds__(WAVE * WPB) void plume_rfew_kernel(PlumeIO io, Radi
                             const double* pb = PB + (smp * R + r) * 3;
                             const double ji = (pb[0] * g1 + pb[1] * g2) + pb[2];
                             lo = fmin(lo, ji);
-                            if (exists) dst[(size_t)j * R + r] = ji;
+                            dst[(size_t)j * R + r] = ji;
                         }
                         part[0] = __builtin_fma(my_w[j].x, g1, part[0]);
                         part[1] = __builtin_fma(my_w[j].y, g1, part[1]);
@@ -1360,19 +1213,34 @@ __global__ __launch_bounds__(WAVE * WPB) void plume_rfew_kernel(PlumeIO io, Radi
                 for (int sh = RF_S; sh < WAVE; sh <<= 1) part[q] += __shfl_xor(part[q], sh);
             }
             if (c == 0) {
-                f64x2* sv = reinterpret_cast<f64x2*>(sums + smp * 4);
-                sv[0] = f64x2{part[0], part[1]};
-                sv[1] = f64x2{part[2], part[3]};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) params[(2 + q) * WAVE + smp] = part[q];
             }
             unsigned long long bad = __ballot(lo <= 0.0);
 #pragma unroll
             for (int sh = RF_S; sh < WAVE; sh <<= 1) bad |= bad >> sh;
             bad = (bad | (a1_nonpos >> (round * RF_S))) & ((1ull << RF_S) - 1);
             inv_mask |= bad << (round * RF_S);
-            if (((bad >> s) & 1) && exists) {   // plume.py:106: the whole block of an invalid sample becomes 1e-20 (rare)
+            if ((bad >> s) & 1) {   // plume.py:106: the whole block of an invalid sample becomes 1e-20 (rare)
                 for (int j = 0; j < RF_CH; ++j)
                     if (k0 + j < NANG)
                         for (int r = 0; r < R; ++r) dst[(size_t)j * R + r] = 1e-20;
+            }
+            {
+                // the round's samples are one contiguous, 16-byte aligned piece of j_ion (round * 8 is even)
+                wave_lds_sync();
+                const long long first = t * WAVE + (long long)round * RF_S;
+                long long valid = (io.n - first) * (long long)blk;          // doubles of this round that exist
+                if (valid > (long long)RF_S * (long long)blk) valid = (long long)RF_S * (long long)blk;
+                if (valid > 0) {
+                    double* out = io.j_ion + (size_t)first * blk;
+                    const int pieces = (int)(valid >> 1);
+                    const f64x2* src2 = reinterpret_cast<const f64x2*>(tile);
+                    f64x2* out2 = reinterpret_cast<f64x2*>(out);
+                    for (int i = lane; i < pieces; i += WAVE) stream_store(src2[i], &out2[i]);
+                    if ((valid & 1) && lane == 0) out[valid - 1] = tile[valid - 1];
+                }
+                wave_lds_sync();   // the tile is rewritten by the next round
             }
         }
         wave_lds_sync();
@@ -1383,12 +1251,12 @@ __global__ __launch_bounds__(WAVE * WPB) void plume_rfew_kernel(PlumeIO io, Radi
             const int smp = idx / R, r = idx - smp * R;
             const unsigned literal = (unsigned)__shfl((int)literal_l, smp);
             const double* pb = PB + idx * 3;
-            const double* sv = sums + smp * 4;
+            const double s1d = params[2 * WAVE + smp], s1n = params[3 * WAVE + smp], s2d = params[4 * WAVE + smp], s2n = params[5 * WAVE + smp];
             double num, den;
             {
 #pragma clang fp contract(off)
-                num = pb[0] * sv[1] + pb[1] * sv[3];
-                den = pb[0] * sv[0] + pb[1] * sv[2];
+                num = pb[0] * s1n + pb[1] * s2n;
+                den = pb[0] * s1d + pb[1] * s2d;
             }
             if ((literal >> r) & 1) {   // the reference's own summation order (amplitudes of opposite sign / near overflow)
 #pragma clang fp contract(off)
@@ -1409,7 +1277,7 @@ __global__ __launch_bounds__(WAVE * WPB) void plume_rfew_kernel(PlumeIO io, Radi
             io.div[(size_t)g * R + r] = acos(cos_div);
             if (have_T) io.Tc[(size_t)g * R + r] = io.T[g] * cos_div;
         }
-        wave_lds_sync();   // params / sums / PB are rewritten by the next tile
+        wave_lds_sync();   // params / PB are rewritten by the next tile
     }
 }
 
@@ -1603,6 +1471,26 @@ int dispatch_lanes(const PlumeIO& io, const CoupledIO& cio, hipStream_t st) {
         case 8: return launch_r1<8, COUPLED, JMODE>(io, cio, st);
         default: return launch_r1<4, COUPLED, JMODE>(io, cio, st);
     }
+}
+
+template <int R>
+int launch_rfew(size_t n, hipStream_t st, const PlumeIO& io, const RadiiSmallArg& ra) {
+    constexpr int NW = rfew_waves<R>();
+    constexpr size_t lds = (size_t)(TABLE_DOUBLES + NW * rfew_wave_doubles<R>()) * 8;
+    static_assert(lds <= 160 * 1024, "the few-radii kernel's workgroup must fit the LDS");
+    if (lds > 64 * 1024) {
+        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(plume_rfew_kernel<R>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        HIP_TRY(attr);
+    }
+    int dev = 0, cus = 256;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const size_t per_cu = (160 * 1024) / lds < 2 ? 1 : 2;          // persistent: workgroups resident per CU
+    size_t grid = ((n + WAVE - 1) / WAVE + NW - 1) / NW;
+    if (grid > (size_t)cus * per_cu) grid = (size_t)cus * per_cu;
+    hipLaunchKernelGGL(plume_rfew_kernel<R>, dim3((unsigned)grid), dim3(WAVE * NW), lds, st, io, ra);
+    return PEM_OK;
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -1819,36 +1707,21 @@ int pem_plume_f64_dev(size_t n, int n_radii, const double* radii, double torr2pa
     PlumeIO io{(long long)n, torr2pa, radii[0], P_b, c0, c1, c2, c3, c4, c5, sigma_cex, I_B0, T, j_ion, div_angle, T_c, invalid};
     if (n_radii == 1 && aligned16(j_ion)) return dispatch_lanes<false, 1>(io, CoupledIO{}, st);
 
-    if (n_radii >= 2 && n_radii <= RADII_SMALL && aligned16(j_ion) && !getenv("PEM_RADII_GENERAL") && !getenv("PEM_RADII_SMALL")) {
+    if (n_radii >= 2 && n_radii <= RADII_SMALL && aligned16(j_ion) && !getenv("PEM_RADII_GENERAL")) {
         // few radii: eight samples per wave in flight, Gaussians by recurrence, profile stored from the angle loop
         RadiiSmallArg ra;
         for (int r = 0; r < RADII_SMALL; ++r) ra.r[r] = r < n_radii ? radii[r] : 1.0;
-        const size_t lds = (size_t)(TABLE_DOUBLES + WPB * (12 * WAVE + 3 * WAVE * n_radii)) * 8;
-        const long long ntiles = (long long)((n + WAVE - 1) / WAVE);
-        unsigned grid = 0;
-        if (int rc = fast_grid((long long)(160 * 1024 / lds) < 3 ? (long long)(160 * 1024 / lds) : 3, ntiles, &grid)) return rc;
+        int rc = PEM_OK;
         switch (n_radii) {
-            case 2: hipLaunchKernelGGL(plume_rfew_kernel<2>, dim3(grid), dim3(WAVE * WPB), lds, st, io, ra); break;
-            case 3: hipLaunchKernelGGL(plume_rfew_kernel<3>, dim3(grid), dim3(WAVE * WPB), lds, st, io, ra); break;
-            case 4: hipLaunchKernelGGL(plume_rfew_kernel<4>, dim3(grid), dim3(WAVE * WPB), lds, st, io, ra); break;
-            case 5: hipLaunchKernelGGL(plume_rfew_kernel<5>, dim3(grid), dim3(WAVE * WPB), lds, st, io, ra); break;
-            case 6: hipLaunchKernelGGL(plume_rfew_kernel<6>, dim3(grid), dim3(WAVE * WPB), lds, st, io, ra); break;
-            case 7: hipLaunchKernelGGL(plume_rfew_kernel<7>, dim3(grid), dim3(WAVE * WPB), lds, st, io, ra); break;
-            default: hipLaunchKernelGGL(plume_rfew_kernel<8>, dim3(grid), dim3(WAVE * WPB), lds, st, io, ra); break;
+            case 2: rc = launch_rfew<2>(n, st, io, ra); break;
+            case 3: rc = launch_rfew<3>(n, st, io, ra); break;
+            case 4: rc = launch_rfew<4>(n, st, io, ra); break;
+            case 5: rc = launch_rfew<5>(n, st, io, ra); break;
+            case 6: rc = launch_rfew<6>(n, st, io, ra); break;
+            case 7: rc = launch_rfew<7>(n, st, io, ra); break;
+            default: rc = launch_rfew<8>(n, st, io, ra); break;
         }
-        HIP_TRY(hipGetLastError());
-        return PEM_OK;
-    }
-    if (n_radii >= 2 && n_radii <= RADII_SMALL && !getenv("PEM_RADII_GENERAL")) {
-        // few radii: the per-radius work of a whole tile at once (R = 2..5: 1.2-2.0 -> ~3 TB/s of output, tools/radii_probe.py)
-        RadiiSmallArg ra;
-        for (int r = 0; r < RADII_SMALL; ++r) ra.r[r] = r < n_radii ? radii[r] : 1.0;
-        int ts = RS_TS;
-        while (ts > 4 && (n + ts - 1) / ts < 256 * 16) ts >>= 1;
-        const size_t ntiles = (n + ts - 1) / ts;
-        size_t blocks = (ntiles + BLOCK / WAVE - 1) / (BLOCK / WAVE);
-        if (blocks > 256 * 2) blocks = 256 * 2;   // persistent: 63 KB of LDS per workgroup, two per CU
-        hipLaunchKernelGGL(plume_radii_small_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, st, io, ra, n_radii, ts);
+        if (rc) return rc;
         HIP_TRY(hipGetLastError());
         return PEM_OK;
     }
