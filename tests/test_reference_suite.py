@@ -3,7 +3,8 @@ of unseeded `np.random.rand`), same assertions, same call signatures.
   tests/test_cathode.py:8-31     -> test_cathode_coupling
   tests/test_plume.py:17-44      -> test_random_samples
   tests/test_plume.py:64-98      -> test_pressure_sweep
-  tests/test_thruster.py:70-114  -> test_sim_hallthruster_stage (the fake-backend run, here the batched test double)
+  tests/test_thruster.py:70-114  -> test_sim_hallthruster_jl (the wrapper, run on the GPU test double) and
+                                    test_sim_hallthruster_stage (the stage alone, batched)
 """
 from typing import cast
 
@@ -75,3 +76,27 @@ def test_sim_hallthruster_stage():
     assert 0 < out['T'][0] < 0.2 and 0 < out['I_B0'][0] < 10 and 0 < out['I_d'][0] < 10
     assert not check_thruster_outputs({k: v[0] if k not in ('u_ion_coords',) else v for k, v in out.items()},
                                       shock_threshold=0.02)
+
+
+def test_sim_hallthruster_jl(tmp_path):
+    """tests/test_thruster.py:70-114 line for line: the reference runs `hallthruster_jl(..., julia_script=tests/
+    sim_hallthruster.jl)`; here the same call (the script's arithmetic is the default backend, evaluated on the GPU) with a
+    dict for the device instead of the downloaded SPT-100 file.  tests/test_hallthruster_jl.py holds the values to what
+    the reference's own function returned."""
+    import json
+    from hallthrusterpem_amd.models import hallthruster_jl
+    thruster_inputs = {'V_a': 250, 'V_cc': 25, 'mdot_a': 3.5e-6}
+    config = {'anom_model': {'type': 'LogisticPressureShift', 'model': {'type': 'TwoZoneBohm', 'c1': 0.008, 'c2': 0.08}},
+              'domain': [0, 0.08]}
+    simulation = {'grid': {'type': 'EvenGrid', 'num_cells': 100}, 'duration': 1e-3, 'dt': 1e-9}
+    postprocess = {'average_start_time': 0.5e-3}
+    outputs = hallthruster_jl(thruster_inputs, config=config, simulation=simulation, thruster={'name': 'SPT-100'},
+                              postprocess=postprocess, julia_script='sim_hallthruster.jl', output_path=tmp_path)
+    outputs = cast(dict, outputs)
+    for key in ['T', 'I_B0', 'I_d', 'u_ion', 'u_ion_coords']:
+        assert key in outputs
+    with open(tmp_path / outputs['output_path'], 'r') as fd:
+        data = json.load(fd)
+        for key in ['thrust', 'ion_current', 'discharge_current', 'mass_eff', 'voltage_eff', 'current_eff']:
+            assert key in data['output']['average']
+    assert data['output']['average']['thrust'] == outputs['T'] and len(data['output']['average']['z']) == len(outputs['u_ion'])
