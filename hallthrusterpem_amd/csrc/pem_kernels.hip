@@ -29,8 +29,9 @@
 //     amplitudes) a chunk is re-evaluated literally (exact_chunk): "equal to the reference" beats "accurate" there.
 //   * The same tile loop carries the fused modes: Monte-Carlo inputs generated in the prelude (MC), the likelihood of
 //     measured current densities (JMODE 3) and the SVD compression (JMODE 4) consuming the profile on chip.
-//   Other kernels in this file: plume_radii_kernel / plume_generic_kernel (sweep_radius arrays), cathode, thruster,
-//   u_ion profile and the post-run filters.
+//   Other kernels in this file: plume_rfew_kernel (2..8 sweep radii: this design generalised), plume_radii_kernel /
+//   plume_generic_kernel (more radii), cathode, thruster, u_ion profile and the post-run filters.  The per-sample scalar
+//   stages and tables are csrc/pem_model.h (shared with the lane-per-sample Saltelli kernel, csrc/pem_saltelli.hip).
 //
 // This file is written for gfx950 only: 64-wide waves, 160 KiB LDS, no portability layer.
 #include <hip/hip_runtime.h>
@@ -156,7 +157,12 @@ __device__ __attribute__((noinline)) double transform_call(int kind, double a, d
 }
 
 // inputs of global sample `g` from the design: bit-identical to pem_sample_f64_dev followed by a load
-__device__ __forceinline__ SampleIn<true> generate_sample(const McDesign& mc, long long g_local) {
+// `design`: the LDS copy of the design's 15 x (a, b, kind) made at kernel start (MC_LDS_DOUBLES: a[15] | b[15] | pad |
+// kind[15] as ints).  Read from the kernel arguments inside the tile loop instead, those 75 SGPRs were spilled to VGPR
+// lanes and restored around every out-of-line transform call: ~370 v_readlane / v_writelane per tile (310 SGPR spills).
+constexpr int MC_LDS_DOUBLES = 48;
+__device__ __forceinline__ SampleIn<true> generate_sample(const McDesign& mc, const double* design, long long g_local) {
+    const int* design_kind = reinterpret_cast<const int*>(design + 32);
     const unsigned long long g = mc.first + (unsigned long long)g_local;
     const unsigned int k0 = (unsigned int)mc.seed, k1 = (unsigned int)(mc.seed >> 32);
     double x[16];
@@ -176,7 +182,7 @@ __device__ __forceinline__ SampleIn<true> generate_sample(const McDesign& mc, lo
         u[2 * pair + 1] = pem::u53(r1.z, r1.w);
     }
 #pragma unroll
-    for (int d = 0; d < 15; ++d) x[d] = transform_call(mc.kind[d], mc.a[d], mc.b[d], u[d]);
+    for (int d = 0; d < 15; ++d) x[d] = transform_call(__builtin_amdgcn_readfirstlane(design_kind[d]), design[d], design[15 + d], u[d]);
     if (mc.x_out) {
 #pragma unroll
         for (int d = 0; d < 15; ++d) mc.x_out[(size_t)d * mc.ld + g_local] = x[d];
@@ -735,6 +741,16 @@ void plume_r1_kernel(PlumeIO io, CoupledIO cio, long long ntiles, DesignArg<MC> 
         }
         m.basis = bas;
     }
+    double* design = nullptr;
+    if constexpr (MC) {   // the Monte-Carlo design behind everything else
+        static_assert(!MC || JMODE == 0 || JMODE == 1, "the fused Monte-Carlo mode writes an fp64 profile or none");
+        design = lds + TABLE_DOUBLES + WPB * wave_lds_doubles<L, JMODE>() + (JMODE == 0 ? QPOLY_DOUBLES : 0);
+        if (tid < 15) {
+            design[tid] = mc.a[tid];
+            design[15 + tid] = mc.b[tid];
+            reinterpret_cast<int*>(design + 32)[tid] = mc.kind[tid];
+        }
+    }
     m.meas = nullptr;
     if constexpr (JMODE == 3) {   // measurement tables behind the per-wave regions (vmcnt is in order: never global)
         double* meas = lds + TABLE_DOUBLES + WPB * wave_lds_doubles<L, JMODE>();
@@ -765,14 +781,14 @@ void plume_r1_kernel(PlumeIO io, CoupledIO cio, long long ntiles, DesignArg<MC> 
     long long t = me;
     if constexpr (MC) {
         for (; t < nfull; t += nwaves) {
-            const SampleIn<COUPLED> in = generate_sample(mc, t * WAVE + lane);
+            const SampleIn<COUPLED> in = generate_sample(mc, design, t * WAVE + lane);
             process_tile<L, COUPLED, JMODE, true>(io, cio, m, in, t, lane, rad, inv_r2, inv_2pi_r2);
         }
         if (nfull < ntiles && (nfull % nwaves) == me) {
             const long long g = nfull * WAVE + lane;
             McDesign quiet = mc;
             if (g >= io.n) quiet.x_out = nullptr;       // dead lanes recompute the last sample and store nothing
-            const SampleIn<COUPLED> in = generate_sample(quiet, g < io.n ? g : io.n - 1);
+            const SampleIn<COUPLED> in = generate_sample(quiet, design, g < io.n ? g : io.n - 1);
             process_tile<L, COUPLED, JMODE, false>(io, cio, m, in, nfull, lane, rad, inv_r2, inv_2pi_r2);
         }
     } else {
@@ -1430,6 +1446,7 @@ int launch_r1(const PlumeIO& io, const CoupledIO& cio, hipStream_t st, const McD
     if (JMODE == 3) lds += (size_t)io.n_cond * (io.n_ang | 1) * 32;
     if (JMODE == 4 || JMODE == 5) lds += (size_t)(96 + 1) * LAT_RT * 8;
     if (JMODE == 0) lds += (size_t)QPOLY_DOUBLES * 8;
+    if (MC) lds += (size_t)MC_LDS_DOUBLES * 8;
     const long long ntiles = (io.n + WAVE - 1) / WAVE;
     unsigned grid = 0;
     auto kern = plume_r1_kernel<L, COUPLED, JMODE, MC>;
