@@ -51,6 +51,7 @@
 #include "pem_hip.h"
 #include "pem_philox.h"
 
+#include "pem_latent.h"
 #include "pem_model.h"
 
 namespace {
@@ -1864,7 +1865,12 @@ int pem_coupled_latent_f64_dev(size_t n, double torr2pa, double radius, const do
     // two forms of the fused compression: 4 = latents accumulated in the registers of the angle loop
     // (default: 386 us per 1.25e6 samples), 5 = profile norm staged in LDS + MFMA contraction (403 us: the 91 log10 per
     // sample bound both, the contraction was not the limiter; profiles/svd_probe_r02i.txt)
-    static const int latent_mode = getenv("PEM_LATENT_MODE") ? atoi(getenv("PEM_LATENT_MODE")) : 4;
+    static const int latent_mode = getenv("PEM_LATENT_MODE") ? atoi(getenv("PEM_LATENT_MODE")) : 6;
+    if (latent_mode == 6) {   // one lane per sample, basis rows through the scalar cache, table log10 (csrc/pem_latent.hip)
+        const pem::LatentArgs la{(long long)n, torr2pa, radius, P_b, V_a, T_e, V_vac, Pstar, P_T, mdot_a, a_1, c0, c1, c2, c3, c4, c5,
+                                 sigma_cex, V_cc, div_angle, T_c, invalid};
+        return pem::launch_coupled_latent(la, rank, norm == PEM_NORM_LOG10, basis, latent, static_cast<hipStream_t>(stream));
+    }
     if (latent_mode == 5) return launch_r1<4, true, 5>(io, cio, static_cast<hipStream_t>(stream));
     return launch_r1<4, true, 4>(io, cio, static_cast<hipStream_t>(stream));
 }

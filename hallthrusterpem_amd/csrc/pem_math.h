@@ -58,6 +58,26 @@ __device__ __forceinline__ double pem_log10_tab(double x, const double* lds_tab)
     return __hiloint2double(ok ? __double2hiint(res) : (int)sp, ok ? __double2loint(res) : 0);
 }
 
+// pem_log10_tab for a POSITIVE FINITE argument (normal or subnormal): the same value bit for bit, without the special
+// cases -- the caller has excluded them (csrc/pem_latent.hip decides them once per sample instead of once per angle).
+__device__ __forceinline__ double pem_log10_tab_pos(double x, const double* lds_tab) {
+    const double m = __builtin_amdgcn_frexp_mant(x);
+    int e = __builtin_amdgcn_frexp_exp(x);
+    const unsigned mh = (unsigned)__double2hiint(m);
+    const int i = (int)((mh >> (20 - PEM_LOG_NBITS)) & (PEM_LOG_N - 1));
+    e -= i < PEM_LOG_LOW_BELOW ? 1 : 0;
+    const log_f64x2 ct = reinterpret_cast<const log_f64x2*>(lds_tab)[i];
+    const double r = fma(m, ct.x, -1.0);
+    double p = PEM_LOG_A6;
+    p = fma(p, r, PEM_LOG_A5);
+    p = fma(p, r, PEM_LOG_A4);
+    p = fma(p, r, PEM_LOG_A3);
+    p = fma(p, r, PEM_LOG_A2);
+    p = fma(p, r, PEM_LOG_A1);
+    const double de = (double)e;
+    return fma(de, 3.01029995663611771306e-01, ct.y) + fma(de, 3.69423907715893078616e-13, p * r);
+}
+
 __device__ __forceinline__ double pem_log10(double x) {
     // v_frexp_{mant,exp}_f64 normalise denormals in hardware: m in [1/2, 1)
     double m = __builtin_amdgcn_frexp_mant(x);
