@@ -27,11 +27,12 @@
 //     Simpson functionals of the beam width (simpson_functionals), per sample, wherever that is exact to rounding.
 //   * Where the reference's own exp() has left the normal range (deep tail of a narrow beam with j_cex = 0, infinite
 //     amplitudes) a chunk is re-evaluated literally (exact_chunk): "equal to the reference" beats "accurate" there.
-//   * The same tile loop carries the fused modes: Monte-Carlo inputs generated in the prelude (MC), the likelihood of
-//     measured current densities (JMODE 3) and the SVD compression (JMODE 4) consuming the profile on chip.
+//   * The same tile loop carries the fused modes: Monte-Carlo inputs generated in the prelude (MC) and the likelihood of
+//     measured current densities (JMODE 3) consuming the profile on chip.  (The fused SVD compression is a lane-per-sample
+//     kernel of its own, csrc/pem_latent.hip.)
 //   Other kernels in this file: plume_rfew_kernel (2..8 sweep radii: this design generalised), plume_radii_kernel /
 //   plume_generic_kernel (more radii), cathode, thruster, u_ion profile and the post-run filters.  The per-sample scalar
-//   stages and tables are csrc/pem_model.h (shared with the lane-per-sample Saltelli kernel, csrc/pem_saltelli.hip).
+//   stages and tables are csrc/pem_model.h (shared with the lane-per-sample kernels, csrc/pem_saltelli.hip and csrc/pem_latent.hip).
 //
 // This file is written for gfx950 only: 64-wide waves, 160 KiB LDS, no portability layer.
 #include <hip/hip_runtime.h>
@@ -51,7 +52,6 @@
 #include "pem_hip.h"
 #include "pem_philox.h"
 
-#include "pem_latent.h"
 #include "pem_model.h"
 
 namespace {
@@ -77,10 +77,6 @@ struct PlumeIO {
     const double *m_wgt, *m_y, *m_inv_std;
     double* loglik;
     int n_cond, n_ang;
-    // fused compression mode (JMODE 4): basis [91][rank] of the SVD map, the norm of the variable, latents [n][rank]
-    const double* basis;
-    double* latent;
-    int rank, log_norm;
 };
 
 struct CoupledIO {
@@ -202,11 +198,8 @@ __device__ __forceinline__ SampleIn<true> generate_sample(const McDesign& mc, co
 //            2: mixed mode -- same fp64 arithmetic, profile rounded once to fp32 when it is staged
 //            3: fused likelihood -- the profile is staged in LDS only and reduced against measured current
 //               densities there (csrc/pem_likelihood.hip's formula); nothing but scalars leaves the chip
-//            4: fused compression -- latent = norm(j_ion) @ basis (csrc/pem_svd.hip's formula) accumulated from the
-//               registers of the angle loop: the profile is neither staged nor stored
-//            5: fused compression, staged -- norm(j_ion) goes to the LDS tile as the profile does in mode 1, and the round's
-//               16 x 91 by 91 x 8 product runs on v_mfma_f64_16x16x4_f64 (the matrix pipe beside the VALU, no basis reads
-//               in the angle loop)
+//            (the fused compression mode -- latent = norm(j_ion) @ basis -- is a kernel of its own, one lane per sample:
+//            csrc/pem_latent.hip)
 // LDS map (doubles): shared by the workgroup: simpson[96][2] | dpoly[32*12];  per wave: params[NROWS][64] |
 // tile[S*91] | 2 (sink).  The Simpson table is padded with zero weights to L*CH <= 96 entries so the angle loop
 // needs no branch.  The den/num partial sums of a round reuse the rows of `params` that the round has consumed.
@@ -214,7 +207,6 @@ __device__ __forceinline__ SampleIn<true> generate_sample(const McDesign& mc, co
 constexpr int NPARAM = 9;   // X1 X2 jcex | r0 G E (beam 1) | r0 G E (beam 2)
 constexpr int NSIMP = 96;   // >= L*CH for L in {2, 4, 8}
 constexpr int WPB = 4;      // waves per workgroup (they share the two tables and nothing else)
-constexpr int LAT_RT = 8;   // latent columns of the fused compression mode (rank <= 8; j_ion needs 5-6 at tol 0.01)
 template <int L>
 constexpr int param_rows() { return 2 * L > NPARAM ? 2 * L : NPARAM; }   // rows 2c, 2c+1 are reused for the Simpson partials
 constexpr int TABLE_DOUBLES = 2 * NSIMP + PEM_NDI * PEM_NDC;
@@ -222,7 +214,7 @@ constexpr int QPOLY_DOUBLES = (PEM_NDI + PEM_NQB) * PEM_NDC * 2;
 template <int L, int JMODE>
 constexpr int wave_lds_doubles() {
     return param_rows<L>() * WAVE +
-           ((JMODE == 1 || JMODE == 3 || JMODE == 5) ? (WAVE / L) * NANG + 2 : JMODE == 2 ? ((WAVE / L) * NANG + 4) / 2 : 0);
+           ((JMODE == 1 || JMODE == 3) ? (WAVE / L) * NANG + 2 : JMODE == 2 ? ((WAVE / L) * NANG + 4) / 2 : 0);
 }
 template <int L, int JMODE>
 constexpr int fast_lds_doubles() { return TABLE_DOUBLES + WPB * wave_lds_doubles<L, JMODE>(); }
@@ -244,14 +236,9 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 #define PEM_NT_STORES 1
 #endif
 // tuning knobs of the fused modes (file scope: a #define inside a function body does not survive -save-temps)
-#ifndef PEM_LATENT_UNROLL
-#define PEM_LATENT_UNROLL 4   // angle-loop unroll of the fused compression mode
-#endif
 #ifndef PEM_LOGLIK_MU
 #define PEM_LOGLIK_MU 2       // measurement records in flight per lane in the fused likelihood mode
 #endif
-// (#pragma unroll takes a constant expression; a macro there is not expanded in preprocessed output)
-constexpr int LATENT_UNROLL = PEM_LATENT_UNROLL;
 __device__ __forceinline__ void stream_store(f64x2 v, f64x2* dst) {
 #if PEM_NT_STORES
     __builtin_nontemporal_store(v, dst);
@@ -262,7 +249,6 @@ __device__ __forceinline__ void stream_store(f64x2 v, f64x2* dst) {
 
 // LDS views of one wave
 struct WaveLds {
-    const double* basis;     // fused compression: [96][LAT_RT] zero-padded basis rows, then colsum[LAT_RT]; or nullptr
     const double* meas;      // fused likelihood: [n_cond*n_ang] records {weight, y, inv_std, k (integer bits)}, or nullptr
     const double2* simpson;  // [96] {cden, cnum}
     const double* poly;      // [32*12]
@@ -301,27 +287,6 @@ __device__ __attribute__((noinline)) ChunkSums exact_chunk(double X1a, double X2
     return r;
 }
 
-// The fused-compression mode's share of the same literal re-evaluation: the chunk's contribution to the latents.
-struct LatSums {
-    double v[8];
-};
-__device__ __attribute__((noinline)) LatSums exact_latents(double X1a, double X2a, double jcex, double a1, double a2, int k0,
-                                                           int nk, const double* basis_rows, int log_norm) {
-#pragma clang fp contract(off)
-    LatSums r;
-    for (int q = 0; q < 8; ++q) r.v[q] = 0.0;
-    for (int j = 0; j < nk; ++j) {
-        const int k = k0 + j;
-        if (k >= NANG) break;
-        const double alpha = k == NANG - 1 ? HALF_PI : (double)k * GRID_H;
-        const double t1 = alpha / a1, t2 = alpha / a2;
-        const double ji = (X1a * exp(-(t1 * t1)) + X2a * exp(-(t2 * t2))) + jcex;
-        const double lj = log_norm ? pem::pem_log10(ji) : ji;
-        for (int q = 0; q < 8; ++q) r.v[q] = __builtin_fma(lj, basis_rows[j * 8 + q], r.v[q]);
-    }
-    return r;
-}
-
 // One 64-sample tile.  FULL = every sample of the tile exists (the steady state of the persistent loop:
 // no bounds checks and a fixed number of stores, so the compiler can count them); FULL = false is the
 // ragged last tile of a batch.
@@ -332,9 +297,7 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
     constexpr int S = WAVE / L;             // samples per round
     constexpr int CH = (NANG + L - 1) / L;  // angles per lane
     constexpr int TILE = S * NANG;          // profile values per round tile
-    constexpr bool WRITE_J = JMODE != 0 && JMODE != 4;
-    constexpr bool LATENT = JMODE == 4;
-    constexpr bool STAGED_LAT = JMODE == 5;      // WRITE_J with norm(j_ion) in the tile instead of j_ion
+    constexpr bool WRITE_J = JMODE != 0;
     using JT = typename std::conditional<JMODE == 2, float, double>::type;   // element type of the stored profile
     constexpr int PER16 = 16 / (int)sizeof(JT);                              // values per 16-byte piece
     constexpr int PAIRS = TILE / PER16;     // 16-byte pieces of a full round tile (TILE divides evenly)
@@ -431,67 +394,14 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
             }
             const double q1 = r01 * r01, q2 = r02 * r02;
             double den = 0.0, num = 0.0, lo = __builtin_inf();   // this lane's chunk of the round (shadows the tile sums)
-            double lat[LATENT ? LAT_RT : 1];
-            if constexpr (LATENT) {
-#pragma unroll
-                for (int r = 0; r < LAT_RT; ++r) lat[r] = 0.0;
-            }
             // The weight reads are issued PF iterations ahead IN SOURCE ORDER: the tile stores in between are
             // LDS stores the compiler must assume may alias the table, so it cannot hoist the reads itself.
             constexpr int PF = 6;
             double2 wq[CH];
-            if constexpr (LATENT) {
-                // a rolled loop: 23 inlined log10 evaluations in one basic block cost 512 registers and scratch
-#pragma unroll LATENT_UNROLL
-                for (int j = 0; j < CH; ++j) {
-                    const double2 w = my_w[j];
-                    const double f = X1 + X2;
-                    const double ji = f + jcex;
-                    const bool in_range = k0 + j < NANG;
-                    lo = fmin(lo, in_range ? f : __builtin_inf());
-                    den = fma(w.x, f, den);
-                    num = fma(w.y, f, num);
-                    // norm(j_ion[k]) times basis row k, straight from the registers; past 90 degrees the basis rows are
-                    // zero, but 0 * log10(0) is not
-                    // (the series log10, not the table one of pem_svd.hip: this loop is bound by its LDS reads of the basis, and a
-                    // per-lane table gather on top of them made it slower -- 457 against 393 us, profiles/svd_probe_r02c.txt)
-                    double lj = io.log_norm ? pem::pem_log10(ji) : ji;
-                    lj = in_range ? lj : 0.0;
-                    const f64x2* brow = reinterpret_cast<const f64x2*>(m.basis + (k0 + j) * LAT_RT);
 #pragma unroll
-                    for (int r = 0; r < LAT_RT; r += 2) {
-                        const f64x2 b = brow[r >> 1];
-                        lat[r] = fma(lj, b.x, lat[r]);
-                        lat[r + 1] = fma(lj, b.y, lat[r + 1]);
-                    }
-                    X1 *= rr1;
-                    rr1 *= q1;
-                    X2 *= rr2;
-                    rr2 *= q2;
-                }
-            }
-            if constexpr (STAGED_LAT) {
-                // rolled like the register-accumulating form above, and for the same reason (23 inlined log10)
-#pragma unroll LATENT_UNROLL
-                for (int j = 0; j < CH; ++j) {
-                    const double2 w = my_w[j];
-                    const double f = X1 + X2;
-                    const double ji = f + jcex;
-                    const bool in_range = k0 + j < NANG;
-                    lo = fmin(lo, in_range ? ji : __builtin_inf());
-                    den = fma(w.x, f, den);
-                    num = fma(w.y, f, num);
-                    tile[in_range ? s * NANG + k0 + j : TILE] = io.log_norm ? pem::pem_log10(ji) : ji;
-                    X1 *= rr1;
-                    rr1 *= q1;
-                    X2 *= rr2;
-                    rr2 *= q2;
-                }
-            }
+            for (int j = 0; WRITE_J && j < PF && j < CH; ++j) wq[j] = my_w[j];
 #pragma unroll
-            for (int j = 0; WRITE_J && !STAGED_LAT && j < PF && j < CH; ++j) wq[j] = my_w[j];
-#pragma unroll
-            for (int j = 0; !LATENT && !STAGED_LAT && j < CH; ++j) {
+            for (int j = 0; j < CH; ++j) {
                 if constexpr (!WRITE_J) wq[j] = my_w[j];   // no tile stores in between: the compiler schedules the reads
                 else if (j + PF < CH) wq[j + PF] = my_w[j + PF];
                 const double f = X1 + X2;     // j_beam + j_scat
@@ -526,16 +436,6 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
                         den = ex.den;
                         num = ex.num;
                         lo = ex.lo;
-                        if constexpr (STAGED_LAT) {   // exact_chunk left j_ion in the tile: the staged form wants its norm
-                            if (io.log_norm)
-                                for (int j = 0; j < CH && k0 + j < NANG; ++j) tile[s * NANG + k0 + j] = pem::pem_log10((double)tile[s * NANG + k0 + j]);
-                        }
-                        if constexpr (LATENT) {
-                            static_assert(LAT_RT == 8, "LatSums carries eight latent columns");
-                            const LatSums el = exact_latents(X1a, X2a, jcex, a1s, a2s, k0, CH, m.basis + k0 * LAT_RT, io.log_norm);
-#pragma unroll
-                            for (int r = 0; r < LAT_RT; ++r) lat[r] = el.v[r];
-                        }
                     }
                 }
             }
@@ -549,58 +449,14 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
             for (int sh = S; sh < WAVE; sh <<= 1) bad |= bad >> sh;   // fold the L chunk lanes of a sample onto bit s
             bad = (bad | (a1_nonpos >> (round * S))) & ((S == 64) ? ~0ull : ((1ull << S) - 1));
             inv_mask |= bad << (round * S);
-            if constexpr (LATENT) {
-                const long long smp_g = t * WAVE + smp;
-                const bool is_bad = (bad >> s) & 1;
-                const double fill = io.log_norm ? -20.0 : 1e-20;   // norm(1e-20): the profile of an invalid sample (plume.py:106)
-#pragma unroll
-                for (int r = 0; r < LAT_RT; ++r) {
-                    double v = lat[r];
-#pragma unroll
-                    for (int sh = S; sh < WAVE; sh <<= 1) v += __shfl_xor(v, sh);   // the L chunk lanes of sample s
-                    if (is_bad) v = fill * m.basis[96 * LAT_RT + r];
-                    if (c == 0 && r < io.rank && (FULL || smp_g < io.n)) io.latent[smp_g * io.rank + r] = v;
-                }
-            }
             if constexpr (WRITE_J) {
                 if ((bad >> s) & 1) {  // plume.py:106: the whole profile of an invalid sample becomes 1e-20 (rare)
-                    const JT fill = (JT)((STAGED_LAT && io.log_norm) ? -20.0 : 1e-20);
+                    const JT fill = (JT)1e-20;
                     for (int j = 0; j < CH; ++j)
                         if (k0 + j < NANG) tile[s * NANG + k0 + j] = fill;
                 }
                 wave_lds_sync();
                 const long long first = t * WAVE + (long long)round * S;
-                if constexpr (STAGED_LAT) {
-                    static_assert(!STAGED_LAT || (L == 4 && LAT_RT == 8), "a round is 16 samples: the rows of one 16x16x4 tile");
-                    // latent[16 samples][8 columns] = tile[16][91] @ basis[91][8] on the matrix pipe: lane (s = row, c = quad) feeds
-                    // A[row][4 step + quad] = tile[row][k] and B[4 step + quad][column = row] (zero for columns 8..15)
-                    const double* ap = reinterpret_cast<const double*>(tile) + s * NANG + c;
-                    const bool bcol = s < LAT_RT;
-                    const double* bp = m.basis + c * LAT_RT + (bcol ? s : 0);
-                    f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                    for (int step = 0; step < 22; step += 2) {
-                        const double a0 = ap[4 * step], a1 = ap[4 * step + 4];
-                        const double b0 = bcol ? bp[4 * step * LAT_RT] : 0.0, b1 = bcol ? bp[(4 * step + 4) * LAT_RT] : 0.0;
-                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
-                    }
-                    {   // step 22: k = 88 + quad, k = 91 does not exist (masked: 0 * inf would be NaN)
-                        const double a = 88 + c < NANG ? ap[88] : 0.0;
-                        const double b = bcol ? bp[88 * LAT_RT] : 0.0;
-                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc0, 0, 0, 0);
-                    }
-                    // lane (row, quad) holds D[quad + 4 i][column = row]
-                    if (s < io.rank) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const long long smp_g = first + c + 4 * i;
-                            if (FULL || smp_g < io.n) io.latent[smp_g * io.rank + s] = acc0[i] + acc1[i];
-                        }
-                    }
-                    wave_lds_sync();
-                    continue;
-                }
                 if constexpr (JMODE == 3) {
                     static_assert(JMODE != 3 || 2 * L < param_rows<L>(), "row 2L of `params` carries the likelihood sum");
                     // measured current densities against the staged profile: lane (s, c) takes measurements c, c+L, ...
@@ -726,21 +582,6 @@ void plume_r1_kernel(PlumeIO io, CoupledIO cio, long long ntiles, DesignArg<MC> 
         double* q = lds + TABLE_DOUBLES + WPB * wave_lds_doubles<L, JMODE>();
         for (int i = tid; i < QPOLY_DOUBLES; i += WAVE * WPB) q[i] = PEM_QPOLY[i];
         m.qpoly = reinterpret_cast<const double2*>(q);
-    }
-    m.basis = nullptr;
-    if constexpr (JMODE == 4 || JMODE == 5) {   // zero-padded basis [96][LAT_RT] + column sums, behind the per-wave regions
-        double* bas = lds + TABLE_DOUBLES + WPB * wave_lds_doubles<L, JMODE>();
-        for (int i = tid; i < 96 * LAT_RT; i += WAVE * WPB) {
-            const int k = i / LAT_RT, r = i - k * LAT_RT;
-            bas[i] = (k < NANG && r < io.rank) ? io.basis[k * io.rank + r] : 0.0;
-        }
-        if (tid < LAT_RT) {
-            double sum = 0.0;
-            if (tid < io.rank)
-                for (int k = 0; k < NANG; ++k) sum += io.basis[k * io.rank + tid];
-            bas[96 * LAT_RT + tid] = sum;
-        }
-        m.basis = bas;
     }
     double* design = nullptr;
     if constexpr (MC) {   // the Monte-Carlo design behind everything else
@@ -1445,7 +1286,6 @@ template <int L, bool COUPLED, int JMODE, bool MC = false>
 int launch_r1(const PlumeIO& io, const CoupledIO& cio, hipStream_t st, const McDesign& mc = McDesign{}) {
     size_t lds = (size_t)fast_lds_doubles<L, JMODE>() * 8;
     if (JMODE == 3) lds += (size_t)io.n_cond * (io.n_ang | 1) * 32;
-    if (JMODE == 4 || JMODE == 5) lds += (size_t)(96 + 1) * LAT_RT * 8;
     if (JMODE == 0) lds += (size_t)QPOLY_DOUBLES * 8;
     if (MC) lds += (size_t)MC_LDS_DOUBLES * 8;
     const long long ntiles = (io.n + WAVE - 1) / WAVE;
@@ -1841,38 +1681,6 @@ int pem_coupled_loglik_f64_dev(size_t n, double torr2pa, double radius, const do
                kidx, weight, y, inv_std, loglik, n_cond, n_ang};
     CoupledIO cio{V_a, T_e, V_vac, Pstar, P_T, mdot_a, a_1, V_cc, nullptr, nullptr};
     return launch_r1<4, true, 3>(io, cio, static_cast<hipStream_t>(stream));
-}
-
-// ---- coupled + SVD compression fused: latent = norm(j_ion) @ basis without the profile ever existing in memory ------
-int pem_coupled_latent_f64_dev(size_t n, double torr2pa, double radius, const double* P_b, const double* V_a,
-                               const double* T_e, const double* V_vac, const double* Pstar, const double* P_T,
-                               const double* mdot_a, const double* a_1, const double* c0, const double* c1, const double* c2,
-                               const double* c3, const double* c4, const double* c5, const double* sigma_cex, int rank,
-                               int norm, const double* basis, double* latent, double* V_cc, double* div_angle, double* T_c,
-                               uint8_t* invalid, pem_stream_t stream) {
-    if (rank < 1 || rank > PEM_FUSED_LATENT_MAX_RANK)
-        return fail(PEM_ERR_INVALID_ARG, "pem_coupled_latent: 1 <= rank <= %d", PEM_FUSED_LATENT_MAX_RANK);
-    if (norm != PEM_NORM_NONE && norm != PEM_NORM_LOG10)
-        return fail(PEM_ERR_INVALID_ARG, "pem_coupled_latent: norm must be PEM_NORM_NONE or PEM_NORM_LOG10");
-    if (n == 0) return PEM_OK;
-    if (!P_b || !V_a || !T_e || !V_vac || !Pstar || !P_T || !mdot_a || !a_1 || !c0 || !c1 || !c2 || !c3 || !c4 || !c5 ||
-        !sigma_cex || !basis || !latent || !V_cc || !div_angle || !T_c)
-        return fail(PEM_ERR_INVALID_ARG, "pem_coupled_latent: NULL array");
-    if (int rc = check_device()) return rc;
-    PlumeIO io{(long long)n, torr2pa, radius, P_b, c0, c1, c2, c3, c4, c5, sigma_cex, nullptr, nullptr, nullptr, div_angle, T_c, invalid, nullptr,
-               nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, basis, latent, rank, norm == PEM_NORM_LOG10 ? 1 : 0};
-    CoupledIO cio{V_a, T_e, V_vac, Pstar, P_T, mdot_a, a_1, V_cc, nullptr, nullptr};
-    // two forms of the fused compression: 4 = latents accumulated in the registers of the angle loop
-    // (default: 386 us per 1.25e6 samples), 5 = profile norm staged in LDS + MFMA contraction (403 us: the 91 log10 per
-    // sample bound both, the contraction was not the limiter; profiles/svd_probe_r02i.txt)
-    static const int latent_mode = getenv("PEM_LATENT_MODE") ? atoi(getenv("PEM_LATENT_MODE")) : 6;
-    if (latent_mode == 6) {   // one lane per sample, basis rows through the scalar cache, table log10 (csrc/pem_latent.hip)
-        const pem::LatentArgs la{(long long)n, torr2pa, radius, P_b, V_a, T_e, V_vac, Pstar, P_T, mdot_a, a_1, c0, c1, c2, c3, c4, c5,
-                                 sigma_cex, V_cc, div_angle, T_c, invalid};
-        return pem::launch_coupled_latent(la, rank, norm == PEM_NORM_LOG10, basis, latent, static_cast<hipStream_t>(stream));
-    }
-    if (latent_mode == 5) return launch_r1<4, true, 5>(io, cio, static_cast<hipStream_t>(stream));
-    return launch_r1<4, true, 4>(io, cio, static_cast<hipStream_t>(stream));
 }
 
 // ---- coupled, mixed precision: fp64 arithmetic, the 91-point profile stored as fp32 -----------------

@@ -3,7 +3,8 @@
 //   latent[i][r] = sum_k norm(j_ion[i][k]) basis[k][r]        (compression.py-shaped map of pem_v0_SPT-100.yml:207-214;
 //                                                              plume.py:39-140 for j_ion, div_angle, T_c)
 //
-// Why a second form beside plume_r1_kernel<4, true, 4> (csrc/pem_kernels.hip), which spreads a sample over four lanes:
+// Why not a mode of plume_r1_kernel (csrc/pem_kernels.hip), which spreads a sample over four lanes (it was one until
+// round 2, 386-406 us per 1.25e6 samples against 185-198 us for this kernel):
 // with four lanes per sample the four chunk lanes of a wave instruction sit at four different angles, so the basis row
 // of "this angle" is per-lane data -- four ds_read_b128 per lane and angle, and the loop was bound by those LDS reads
 // (a per-lane log10 table gather on top of them made it slower; profiles/svd_probe_r02c.txt).  With one lane per
@@ -24,7 +25,6 @@
 
 #include "pem_common.h"
 #include "pem_hip.h"
-#include "pem_latent.h"
 #include "pem_math.h"
 #include "pem_model.h"
 
@@ -32,8 +32,27 @@ namespace {
 
 using namespace pem_model;
 
+struct LatentArgs {
+    long long n;
+    double torr2pa, radius;
+    const double *P_b, *V_a, *T_e, *V_vac, *Pstar, *P_T, *mdot_a, *a_1, *c0, *c1, *c2, *c3, *c4, *c5, *sigma;
+    double *V_cc, *div, *Tc;
+    uint8_t* invalid;
+};
+
 constexpr int CHUNK = 23;          // angles between restarts of the recurrences = the chunk of plume_r1_kernel<4, ...>
-constexpr int LAT_BLOCK = 256;
+// tuning knobs (tools/build_variant.sh -DPEM_LAT_...=; #pragma unroll wants a constant expression, not a macro)
+#ifndef PEM_LAT_BLOCK
+#define PEM_LAT_BLOCK 256
+#endif
+#ifndef PEM_LAT_UNROLL
+#define PEM_LAT_UNROLL 2
+#endif
+#ifndef PEM_LAT_WAVES
+#define PEM_LAT_WAVES 4      // waves per SIMD the register allocator leaves room for
+#endif
+constexpr int LAT_BLOCK = PEM_LAT_BLOCK;
+constexpr int LAT_UNROLL = PEM_LAT_UNROLL;
 constexpr int OUT_STRIDE = 65;     // doubles per column of a wave's output staging block (odd: the transposed reads spread over the banks)
 typedef double lat_f64x2 __attribute__((ext_vector_type(2)));
 
@@ -75,7 +94,7 @@ __device__ __attribute__((noinline)) void literal_sample(double X1a, double X2a,
 }
 
 template <int RANK, bool LOGN>
-__global__ __launch_bounds__(LAT_BLOCK) void coupled_latent_kernel(pem::LatentArgs a, const double* __restrict__ basis,
+__global__ __launch_bounds__(LAT_BLOCK) __attribute__((amdgpu_waves_per_eu(PEM_LAT_WAVES))) void coupled_latent_kernel(LatentArgs a, const double* __restrict__ basis,
                                                                     double* __restrict__ latent) {
     __shared__ __attribute__((aligned(16))) double logtab[LOGN ? pem::LOG_TABLE_DOUBLES : 2];
     __shared__ __attribute__((aligned(16))) double outbuf[LAT_BLOCK / 64][RANK * OUT_STRIDE];   // per wave: [column][sample]
@@ -126,7 +145,7 @@ __global__ __launch_bounds__(LAT_BLOCK) void coupled_latent_kernel(pem::LatentAr
     for (int c = 0; c < 4; ++c) {
         double X1 = Xc1, X2 = Xc2, rr1 = rc1, rr2 = rc2, dc = 0.0, nc = 0.0;
         const int k0 = c * CHUNK, nk = c < 3 ? CHUNK : NANG - 3 * CHUNK;
-#pragma unroll 2
+#pragma unroll LAT_UNROLL
         for (int j = 0; j < nk; ++j) {
             const int k = k0 + j;                       // wave-uniform: weights and basis row are scalar loads
             const double f = X1 + X2;                   // j_beam + j_scat
@@ -214,7 +233,7 @@ __global__ __launch_bounds__(LAT_BLOCK) void coupled_latent_kernel(pem::LatentAr
 }
 
 template <int RANK>
-int launch_rank(const pem::LatentArgs& a, const double* basis, double* latent, bool log_norm, hipStream_t st) {
+int launch_rank(const LatentArgs& a, const double* basis, double* latent, bool log_norm, hipStream_t st) {
     const unsigned blocks = (unsigned)((a.n + LAT_BLOCK - 1) / LAT_BLOCK);
     if (log_norm) hipLaunchKernelGGL((coupled_latent_kernel<RANK, true>), dim3(blocks), dim3(LAT_BLOCK), 0, st, a, basis, latent);
     else hipLaunchKernelGGL((coupled_latent_kernel<RANK, false>), dim3(blocks), dim3(LAT_BLOCK), 0, st, a, basis, latent);
@@ -224,9 +243,27 @@ int launch_rank(const pem::LatentArgs& a, const double* basis, double* latent, b
 
 }  // namespace
 
-namespace pem {
+extern "C" {
 
-int launch_coupled_latent(const LatentArgs& a, int rank, bool log_norm, const double* basis, double* latent, hipStream_t st) {
+int pem_coupled_latent_f64_dev(size_t n, double torr2pa, double radius, const double* P_b, const double* V_a,
+                               const double* T_e, const double* V_vac, const double* Pstar, const double* P_T,
+                               const double* mdot_a, const double* a_1, const double* c0, const double* c1, const double* c2,
+                               const double* c3, const double* c4, const double* c5, const double* sigma_cex, int rank,
+                               int norm, const double* basis, double* latent, double* V_cc, double* div_angle, double* T_c,
+                               uint8_t* invalid, pem_stream_t stream) {
+    if (rank < 1 || rank > PEM_FUSED_LATENT_MAX_RANK)
+        return pem::fail(PEM_ERR_INVALID_ARG, "pem_coupled_latent: 1 <= rank <= %d", PEM_FUSED_LATENT_MAX_RANK);
+    if (norm != PEM_NORM_NONE && norm != PEM_NORM_LOG10)
+        return pem::fail(PEM_ERR_INVALID_ARG, "pem_coupled_latent: norm must be PEM_NORM_NONE or PEM_NORM_LOG10");
+    if (n == 0) return PEM_OK;
+    if (!P_b || !V_a || !T_e || !V_vac || !Pstar || !P_T || !mdot_a || !a_1 || !c0 || !c1 || !c2 || !c3 || !c4 || !c5 ||
+        !sigma_cex || !basis || !latent || !V_cc || !div_angle || !T_c)
+        return pem::fail(PEM_ERR_INVALID_ARG, "pem_coupled_latent: NULL array");
+    if (int rc = pem::check_device()) return rc;
+    const LatentArgs a{(long long)n, torr2pa, radius, P_b, V_a, T_e, V_vac, Pstar, P_T, mdot_a, a_1, c0, c1, c2, c3, c4, c5,
+                       sigma_cex, V_cc, div_angle, T_c, invalid};
+    const bool log_norm = norm == PEM_NORM_LOG10;
+    hipStream_t st = static_cast<hipStream_t>(stream);
     switch (rank) {
         case 1: return launch_rank<1>(a, basis, latent, log_norm, st);
         case 2: return launch_rank<2>(a, basis, latent, log_norm, st);
@@ -235,9 +272,8 @@ int launch_coupled_latent(const LatentArgs& a, int rank, bool log_norm, const do
         case 5: return launch_rank<5>(a, basis, latent, log_norm, st);
         case 6: return launch_rank<6>(a, basis, latent, log_norm, st);
         case 7: return launch_rank<7>(a, basis, latent, log_norm, st);
-        case 8: return launch_rank<8>(a, basis, latent, log_norm, st);
+        default: return launch_rank<8>(a, basis, latent, log_norm, st);
     }
-    return fail(PEM_ERR_INVALID_ARG, "pem_coupled_latent: 1 <= rank <= %d", PEM_FUSED_LATENT_MAX_RANK);
 }
 
-}  // namespace pem
+}  // extern "C"

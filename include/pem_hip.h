@@ -194,8 +194,8 @@ int pem_coupled_loglik_f64_dev(size_t n, double torr2pa, double radius, const do
                                double* div_angle, double* T_c, double* loglik, uint8_t* invalid, pem_stream_t stream);
 
 /* pem_coupled_f64_dev + pem_svd_compress_f64_dev in one launch: latent[i][r] = sum_k norm(j_ion[i][k]) basis[k][r]
- * accumulated in the registers of the angle loop -- the profile is neither stored nor staged (120 + 24 + 8 rank bytes
- * per evaluation).  norm: PEM_NORM_NONE or PEM_NORM_LOG10; basis: [91][rank] device array, rank <=
+ * accumulated in the registers of the angle loop, one lane per sample (csrc/pem_latent.hip) -- the profile is neither
+ * stored nor staged (120 + 24 + 8 rank bytes per evaluation).  norm: PEM_NORM_NONE or PEM_NORM_LOG10; basis: [91][rank] device array, rank <=
  * PEM_FUSED_LATENT_MAX_RANK; latent: [n][rank].  An invalid sample gets the latents of its 1e-20 profile
  * (plume.py:106), as the two-launch pipeline gives.                                                               */
 #define PEM_FUSED_LATENT_MAX_RANK 8
