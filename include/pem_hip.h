@@ -242,8 +242,10 @@ int pem_svd_reconstruct_f64_dev(size_t n, int dof, int rank, int norm, double no
  * formula in csrc/pem_surrogate.hip, tables built by hallthrusterpem_amd/surrogate.py.
  *   out[o][i] = sum_b coef[b] * sum_nodes values[offset_b + node][o] * prod_a basis(level_a, t[dim_a][i])
  * index: [n_beta][2 + 2*PEM_SURR_MAX_ACTIVE] int32 = {n_active, value offset (rows), dims[], levels[]};
- * values: [rows][n_out]; t: [n_dim][ld] normalised coordinates in [-1, 1]; out: [n_out][ld_out]; n_out <= 16.   */
+ * values: [rows][n_out]; t: [n_dim][ld] normalised coordinates in [-1, 1], n_dim <= PEM_SURR_MAX_DIM;
+ * out: [n_out][ld_out]; n_out <= 16.                                                                        */
 #define PEM_SURR_MAX_ACTIVE 3
+#define PEM_SURR_MAX_DIM 32
 int pem_sparse_predict_f64_dev(size_t n, int n_dim, int n_beta, const int32_t* index, const double* coef,
                                const double* values, int n_out, const double* t, size_t ld, double* out,
                                size_t ld_out, pem_stream_t stream);

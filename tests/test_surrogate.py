@@ -84,3 +84,52 @@ def test_adaptive_refinement_reduces_error_against_true_model():
     # V_cc does not depend on the plume coefficients: refinement in those dimensions never helps V_cc
     first = [h[0] for h in hist]
     assert any(b[1] > 0 or b[0] > 0 for b in first)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n_out', [1, 2, 4, 5, 9, 16])
+def test_predict_kernel_synthetic_tables_all_output_widths(n_out):
+    """pem_sparse_predict_f64_dev through the C ABI on hand-made tables: 15 dimensions (the coordinate staging then needs more
+    than 64 KB of LDS), every register width of the kernel (exact 1..4, guarded 8 / 16), grids up to 9 x 9 x 9 nodes, a
+    point count that is not a multiple of the workgroup."""
+    import ctypes as C
+    import torch
+    from hallthrusterpem_amd import _lib
+    from oracle import surrogate_np as snp
+    D, n = 15, 1000
+    rng = np.random.default_rng(n_out)
+    betas = [(0,) * D]
+    for dims, levels in [((0,), (1,)), ((14,), (3,)), ((3, 9), (2, 1)), ((1, 2, 3), (1, 1, 1)), ((5, 6, 14), (3, 3, 3)),
+                         ((0, 7, 13), (1, 3, 2)), ((10, 11), (3, 3))]:
+        b = [0] * D
+        for d, l in zip(dims, levels):
+            b[d] = l
+        betas.append(tuple(b))
+    values = {b: rng.standard_normal((int(np.prod([snp.nodes(l).size for l in b])), n_out)) for b in betas}
+    coefs = {b: float(c) for b, c in zip(betas, rng.integers(-3, 4, len(betas)))}
+    coefs[betas[0]] = 1.0
+    used = [b for b in betas if coefs[b] != 0]
+    idx = np.zeros((len(used), 8), dtype=np.int32)
+    off = 0
+    for i, b in enumerate(used):
+        active = [d for d in range(D) if b[d] > 0]
+        idx[i, 0], idx[i, 1] = len(active), off
+        for a, d in enumerate(active):
+            idx[i, 2 + a], idx[i, 5 + a] = d, b[d]
+        off += values[b].shape[0]
+    t = rng.uniform(-1, 1, (D, n))
+    t[:, 0] = 0.0
+    t[14, 1], t[5, 2] = 1.0, -np.cos(np.pi / 8)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()                   # noqa: E731
+    d_idx, d_coef = dev(idx), dev(np.array([coefs[b] for b in used]))
+    d_val, d_t = dev(np.concatenate([values[b] for b in used])), dev(t)
+    out = torch.full((n_out, n + 7), np.nan, dtype=torch.float64, device='cuda')
+    p = lambda x: C.c_void_p(x.data_ptr())                                               # noqa: E731
+    _lib.check(_lib.load().pem_sparse_predict_f64_dev(n, D, len(used), p(d_idx), p(d_coef), p(d_val), n_out, p(d_t), n, p(out), n + 7,
+                                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert np.isnan(got[:, n:]).all()                                    # nothing written past the n points of a row
+    want = snp.predict(used, coefs, values, t)
+    assert np.max(np.abs(got[:, :n] - want) / np.abs(want).max(axis=1, keepdims=True)) < 1e-12
+    assert _lib.load().pem_sparse_predict_f64_dev(n, 33, len(used), p(d_idx), p(d_coef), p(d_val), n_out, p(d_t), n, p(out), n + 7, None) != 0

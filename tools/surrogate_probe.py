@@ -37,5 +37,8 @@ truth = batch.qoi.clone()
 pred = s.predict(t)
 err = (torch.linalg.norm(pred - truth, dim=1) / torch.linalg.norm(truth, dim=1)).cpu().numpy()
 nb = s._tables[3]
+nodes_total = int(s._tables[2].numel() // len(s.qoi))
+levels = s._tables[0].cpu().numpy()[:, 2 + 3:2 + 6]
+print(f'combination: {nb} grids, {nodes_total} grid nodes in total (sum of the grids\' sizes) -> {nodes_total * len(s.qoi)} FMAs per point; level histogram of active dims {np.bincount(levels[levels > 0].ravel())}')
 print(f'5e5 candidate points: true model (reduced QoIs) {ms_m*1e3:.1f} us = {n/ms_m/1e6:.2f} G evals/s | surrogate predict '
       f'({nb} grids in the combination) {ms_p*1e3:.1f} us = {n/ms_p/1e6:.2f} G points/s | relative L2 error {err}')
