@@ -140,3 +140,32 @@ def test_fused_coupled_compression_matches_two_launch_pipeline(n, norm):
         big = SVDCompression(norm=norm, rank=9)
         big.basis = torch.zeros((91, 9), dtype=torch.float64, device='cuda')
         fused.run_latent(big)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rank', [1, 2, 3, 5, 7, 8])
+def test_fused_coupled_compression_every_rank(rank):
+    """coupled_latent_kernel<RANK, LOGN> (csrc/pem_latent.hip) is instantiated per rank: every one against the two-launch
+    pipeline, on a batch with whole waves (coalesced 16-byte pieces through LDS) and a ragged tail (per-lane stores)."""
+    import torch
+    from hallthrusterpem_amd.batch import CoupledBatch
+    from hallthrusterpem_amd.compression import SVDCompression
+    from hallthrusterpem_amd.sampling import Design
+    n = 64 * 5 + 37
+    basis = np.linalg.qr(np.random.default_rng(rank).standard_normal((91, rank)))[0]
+    for norm in ('log10', 'none'):
+        c = SVDCompression(norm=norm, rank=rank)
+        c.basis = torch.from_numpy(np.ascontiguousarray(basis)).cuda()
+        ref = CoupledBatch(n, profile=True, thruster_qoi=False)
+        Design(seed=40 + rank).fill(ref.inputs)
+        ref.inputs[10, 70:73], ref.inputs[11, 70:73] = 0.0, -1.0       # alpha1 = c3 <= 0: invalid, profile 1e-20
+        ref.run()
+        want = c.compress(ref.j_ion)
+        fused = CoupledBatch(n, profile=False, thruster_qoi=False)
+        fused.inputs.copy_(ref.inputs)
+        out = torch.full((n + 3, rank), float('nan'), dtype=torch.float64, device='cuda')
+        got = fused.run_latent(c, out=out[:n])
+        torch.cuda.synchronize()
+        assert torch.isnan(out[n:]).all()                              # nothing written behind the batch
+        assert float((got - want).abs().max()) <= 1e-12 * max(1.0, float(want.abs().max()))
+        assert torch.equal(ref.invalid, fused.invalid) and bool(ref.invalid[70:73].all())
