@@ -85,18 +85,24 @@ class CoupledBatch:
         rc = fn(count, constants.TORR_2_PA, self.radius, *ins, *outs, C.c_void_p(s.cuda_stream))
         _lib.check(rc)
 
-    def run_mc(self, design, first_index: int = 0, write_inputs: bool = False, swap_dim: int = -1, stream=None):
-        """Fused Monte-Carlo step: generate samples first_index .. first_index+n-1 of `design` (a sampling.Design over
-        the 15 coupled inputs) inside the kernel and evaluate them; `write_inputs` also stores them in `self.inputs`."""
+    def run_mc(self, design, first_index: int = 0, write_inputs: bool = False, swap_dim: int = -1, stream=None,
+               first: int = 0, count: int | None = None):
+        """Fused Monte-Carlo step: generate samples first_index .. first_index+count-1 of `design` (a sampling.Design over
+        the 15 coupled inputs) inside the kernel and evaluate them into samples first .. first+count-1 of this batch (default:
+        the whole batch); `write_inputs` also stores them in `self.inputs`.  `first` must be even, as for `run`."""
         import torch
         s = torch.cuda.current_stream(self.device) if stream is None else stream
         if self.mixed:
             raise NotImplementedError('fused Monte-Carlo mode writes an fp64 profile or none')
+        count = self.n - first if count is None else int(count)
+        if first < 0 or count < 0 or first + count > self.n or first & 1:
+            raise ValueError(f'range [{first}, {first + count}) does not fit a batch of {self.n} samples or starts at an odd sample')
+        outs = self._out_ptrs if first == 0 else self._range_ptrs(int(first))[1]
         ptr = lambda arr: C.c_void_p(arr.ctypes.data)                                           # noqa: E731
         rc = _lib.load().pem_coupled_mc_f64_dev(
-            self.n, int(first_index), design.seed, design.stream, int(swap_dim), ptr(design.kind), ptr(design.a), ptr(design.b),
-            constants.TORR_2_PA, self.radius, C.c_void_p(self.inputs.data_ptr()) if write_inputs else None,
-            self.inputs.stride(0), *self._out_ptrs, C.c_void_p(s.cuda_stream))
+            count, int(first_index), design.seed, design.stream, int(swap_dim), ptr(design.kind), ptr(design.a), ptr(design.b),
+            constants.TORR_2_PA, self.radius, C.c_void_p(self.inputs.data_ptr() + 8 * int(first)) if write_inputs else None,
+            self.inputs.stride(0), *outs, C.c_void_p(s.cuda_stream))
         _lib.check(rc)
 
     def run_loglik(self, likelihood, out=None, stream=None):
