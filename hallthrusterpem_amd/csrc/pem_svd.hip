@@ -234,6 +234,10 @@ __global__ __launch_bounds__(BLOCK) void svd_compress_kernel(long long n, int do
 // kernel at two waves per SIMD: this one is limited by its ~140 registers (three waves per SIMD), so one wave's loads are
 // in flight while the others take logs.
 constexpr int DIRECT_STEPS = 24;     // dof <= 96
+// Which k the matrix pipe's slot (step, quad) carries.  Any one-to-one map will do as long as A and B agree; this one gives a
+// lane two CONSECUTIVE k per pair of steps -- k = 8 (step / 2) + 2 quad + (step & 1) -- so that it loads them with one 16-byte
+// instruction: 12 loads of 16 rows x 64 contiguous bytes per tile instead of 24 of 16 x 32.
+__device__ __forceinline__ constexpr int direct_k(int step, int quad) { return 8 * (step >> 1) + 2 * quad + (step & 1); }
 // BREG: the lane's 24 basis values live in registers for the whole launch (160 VGPRs, three waves per SIMD); otherwise they
 // are re-read from LDS per tile (conflict-free 8-byte reads) and the kernel is compiled for four waves per SIMD.
 template <int MODE, bool BREG>
@@ -257,26 +261,38 @@ void svd_compress_direct_kernel(long long n, int dof, int r, double scale, const
     if constexpr (BREG) {
 #pragma unroll
         for (int step = 0; step < DIRECT_STEPS; ++step) {
-            const int k = 4 * step + quad;
+            const int k = direct_k(step, quad);
             b[step] = (k < dof && row < r) ? basis[(size_t)k * r + row] : 0.0;
         }
     }
-    const double* bl = bas + quad * 16 + row;
+    const double* bl = bas + row;
     const long long ntiles = (n + 15) / 16;
     const long long stride = (long long)gridDim.x * WAVES;
     for (long long t = (long long)blockIdx.x * WAVES + wave; t < ntiles; t += stride) {
         const long long s0 = t * 16;
         const long long smp = s0 + row < n ? s0 + row : n - 1;         // rows past the batch repeat its last sample
-        const double* src = field + smp * dof + quad;
+        const double* src = field + smp * dof;
         double a[DIRECT_STEPS];
+        constexpr double PAD = MODE == PEM_NORM_LOG10 ? 1.0 : 0.0;
 #pragma unroll
-        for (int step = 0; step < DIRECT_STEPS; ++step) a[step] = 4 * step + quad < dof ? src[4 * step] : (MODE == PEM_NORM_LOG10 ? 1.0 : 0.0);
+        for (int step = 0; step < DIRECT_STEPS; step += 2) {       // two consecutive k per lane: one 16-byte load
+            const int k = direct_k(step, quad);
+            if (k + 1 < dof) {
+                typedef double f64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));   // rows of an odd dof start 8 bytes off
+                const f64x2_a8 v = *reinterpret_cast<const f64x2_a8*>(src + k);
+                a[step] = v.x;
+                a[step + 1] = v.y;
+            } else {
+                a[step] = k < dof ? src[k] : PAD;
+                a[step + 1] = PAD;
+            }
+        }
         f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int step = 0; step < DIRECT_STEPS; step += 2) {
             // k >= dof: the value is 0 AFTER the norm (log10(1) = 0 exactly), and it meets a zero basis row
             const double l0 = norm_fwd<MODE>(scale, a[step], logtab), l1 = norm_fwd<MODE>(scale, a[step + 1], logtab);
-            const double b0 = BREG ? b[BREG ? step : 0] : bl[64 * step], b1 = BREG ? b[BREG ? step + 1 : 0] : bl[64 * step + 64];
+            const double b0 = BREG ? b[BREG ? step : 0] : bl[16 * direct_k(step, quad)], b1 = BREG ? b[BREG ? step + 1 : 0] : bl[16 * direct_k(step + 1, quad)];
             acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(l0, b0, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(l1, b1, acc1, 0, 0, 0);
         }
