@@ -1278,6 +1278,14 @@ int fast_grid(long long per_cu, long long ntiles, unsigned* grid) {
     long long g = (long long)cus[dev] * per_cu;
     const long long need = (ntiles + WPB - 1) / WPB;
     if (g > need) g = need;
+    // Balanced rounds: a persistent wave takes tiles me, me + nwaves, ...; with the full grid a 1.25e6-sample shard is 9.54 tiles
+    // per wave -- ten rounds, the last one 54 % full and as long as a full one (a tile's duration is latency, not bandwidth:
+    // tools/tail_probe.py).  The smallest grid with the same number of rounds fills every round instead.
+    static const bool balanced = getenv("PEM_BALANCED_GRID") ? atoi(getenv("PEM_BALANCED_GRID")) != 0 : true;
+    if (balanced && g > 0) {
+        const long long rounds = (need + g - 1) / g;
+        g = (need + rounds - 1) / rounds;
+    }
     *grid = (unsigned)g;
     return PEM_OK;
 }

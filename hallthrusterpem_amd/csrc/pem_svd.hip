@@ -308,7 +308,10 @@ void svd_compress_direct_kernel(long long n, int dof, int r, double scale, const
 }
 
 // LDS: basis_t[16][dof_p] with dof_p = 16*ceil(dof/16) (zero padded) | per wave: tile[16*dof] (+2)
-template <int MODE>
+// BREG (dof <= 96): the lane's B operands -- basis[angle 16 g + row][4 step + quad], 6 groups x 4 steps -- stay in registers for
+// the whole launch instead of being re-read from LDS per tile: the workgroup's LDS is then the four tiles only (46.6 instead
+// of 58.7 KB) and three workgroups fit a CU instead of two.
+template <int MODE, bool BREG>
 __global__ __launch_bounds__(BLOCK) void svd_reconstruct_kernel(long long n, int dof, int r, double scale,
                                                                 const double* __restrict__ latent,
                                                                 const double* __restrict__ basis,
@@ -316,19 +319,33 @@ __global__ __launch_bounds__(BLOCK) void svd_reconstruct_kernel(long long n, int
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* lds = reinterpret_cast<double*>(smem_raw);
     const int groups = (dof + 15) / 16, dof_p = groups * 16;
-    double* basis_t = lds;                                   // [16][dof_p]: basis_t[j][k] = basis[k][j]
+    double* basis_t = lds;                                   // [16][dof_p]: basis_t[j][k] = basis[k][j] (not with BREG)
     const int tile_doubles = (16 * dof + 3) & ~1;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    double* tile = lds + 16 * dof_p + wave * tile_doubles;
-    for (int i = tid; i < 16 * dof_p; i += BLOCK) {
-        const int j = i / dof_p, k = i - j * dof_p;
-        basis_t[i] = (k < dof && j < r) ? basis[(size_t)k * r + j] : 0.0;
-    }
-    __syncthreads();
-
+    double* tile = lds + (BREG ? 0 : 16 * dof_p) + wave * tile_doubles;
     const int row = lane & 15, quad = lane >> 4;
+    constexpr int RGROUPS = 6;                               // dof <= 96
+    double breg[BREG ? RGROUPS * 4 : 1];
+    if constexpr (BREG) {
+#pragma unroll
+        for (int g = 0; g < RGROUPS; ++g) {
+#pragma unroll
+            for (int step = 0; step < 4; ++step) {
+                const int k = 16 * g + row, j = 4 * step + quad;
+                breg[g * 4 + step] = (k < dof && j < r) ? basis[(size_t)k * r + j] : 0.0;
+            }
+        }
+    } else {
+        for (int i = tid; i < 16 * dof_p; i += BLOCK) {
+            const int j = i / dof_p, k = i - j * dof_p;
+            basis_t[i] = (k < dof && j < r) ? basis[(size_t)k * r + j] : 0.0;
+        }
+        __syncthreads();
+    }
+
     const long long ntiles = (n + 15) / 16;
     const long long stride = (long long)gridDim.x * WAVES;
+    const int ksteps = (r + 3) >> 2;      // k-steps of four latent columns that hold any: 2 of 4 for rank 5..8 (the rest multiplies zeros)
     for (long long t = (long long)blockIdx.x * WAVES + wave; t < ntiles; t += stride) {
         const long long s0 = t * 16;
         // A fragments: latent[s0 + row][4 step + quad], 4 k-steps cover the 16 padded latent columns
@@ -339,17 +356,31 @@ __global__ __launch_bounds__(BLOCK) void svd_reconstruct_kernel(long long n, int
             const int j = 4 * step + quad;
             a[step] = (j < r && smp_a < n) ? latent[smp_a * r + j] : 0.0;
         }
-        for (int g = 0; g < groups; ++g) {
+        auto one_group = [&](int g, const double (&b)[4]) {
             f64x4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int step = 0; step < 4; ++step) {
-                const double b = basis_t[(4 * step + quad) * dof_p + 16 * g + row];   // B[j][angle 16 g + (lane & 15)]
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[step], b, acc, 0, 0, 0);
-            }
+            for (int step = 0; step < 4; ++step)
+                if (step < ksteps) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[step], b[step], acc, 0, 0, 0);
             const int k = 16 * g + row;
             if (k < dof) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) tile[(quad + 4 * i) * dof + k] = acc[i];
+            }
+        };
+        if constexpr (BREG) {
+#pragma unroll
+            for (int g = 0; g < RGROUPS; ++g) {
+                if (g < groups) {
+                    const double b[4] = {breg[BREG ? g * 4 : 0], breg[BREG ? g * 4 + 1 : 0], breg[BREG ? g * 4 + 2 : 0], breg[BREG ? g * 4 + 3 : 0]};
+                    one_group(g, b);
+                }
+            }
+        } else {
+            for (int g = 0; g < groups; ++g) {
+                double b[4];
+#pragma unroll
+                for (int step = 0; step < 4; ++step) b[step] = basis_t[(4 * step + quad) * dof_p + 16 * g + row];   // B[j][angle 16 g + (lane & 15)]
+                one_group(g, b);
             }
         }
         wave_lds_sync();
@@ -381,9 +412,9 @@ int check_args(const char* who, size_t n, int dof, int r, int mode, const void* 
     return PEM_OK;
 }
 
-unsigned grid_for(size_t n) {
+unsigned grid_for(size_t n, int per_cu = 2) {
     size_t tiles = (n + 15) / 16, blocks = (tiles + WAVES - 1) / WAVES;
-    if (blocks > 256 * 2) blocks = 256 * 2;     // persistent: LDS admits 1-2 workgroups per CU
+    if (blocks > 256 * (size_t)per_cu) blocks = 256 * (size_t)per_cu;     // persistent: LDS admits 1-3 workgroups per CU
     return (unsigned)(blocks ? blocks : 1);
 }
 
@@ -468,19 +499,28 @@ int pem_svd_reconstruct_f64_dev(size_t n, int dof, int rank, int norm, double no
     // (A direct form -- denorm and 8-byte stores straight from the MFMA result registers, no LDS tile -- was measured and
     // dropped: 16 lanes write 128 contiguous bytes, but a 728-byte profile row puts those pieces across cache lines, and the
     // kernel ran at 1.4-1.5 TB/s against 3.9 / 5.6 TB/s for the staged form below; profiles/svd_probe_r02k.txt.)
-    const size_t lds = ((size_t)16 * (((dof + 15) / 16) * 16) + (size_t)WAVES * ((16 * dof + 3) & ~1)) * 8;
-#define PEM_SVD_RLAUNCH(MODE_)                                                                                       \
+    static const bool rbreg_env = getenv("PEM_SVD_RBREG") ? atoi(getenv("PEM_SVD_RBREG")) != 0 : true;
+    const bool rbreg = rbreg_env && dof <= 96;
+    const size_t lds = ((rbreg ? 0 : (size_t)16 * (((dof + 15) / 16) * 16)) + (size_t)WAVES * ((16 * dof + 3) & ~1)) * 8;
+    const unsigned rgrid = grid_for(n, rbreg ? 3 : 2);       // persistent: workgroups per CU that the LDS admits
+#define PEM_SVD_RLAUNCH2(MODE_, BREG_)                                                                               \
     do {                                                                                                             \
-        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(svd_reconstruct_kernel<MODE_>),   \
+        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(svd_reconstruct_kernel<MODE_, BREG_>), \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);        \
         HIP_TRY(attr);                                                                                               \
-        hipLaunchKernelGGL((svd_reconstruct_kernel<MODE_>), dim3(grid_for(n)), dim3(BLOCK), lds,                     \
+        hipLaunchKernelGGL((svd_reconstruct_kernel<MODE_, BREG_>), dim3(rgrid), dim3(BLOCK), lds,                    \
                            static_cast<hipStream_t>(stream), (long long)n, dof, rank, norm_scale, latent, basis, field); \
+    } while (0)
+#define PEM_SVD_RLAUNCH(MODE_)                            \
+    do {                                                  \
+        if (rbreg) PEM_SVD_RLAUNCH2(MODE_, true);         \
+        else PEM_SVD_RLAUNCH2(MODE_, false);              \
     } while (0)
     if (norm == PEM_NORM_LOG10) PEM_SVD_RLAUNCH(PEM_NORM_LOG10);
     else if (norm == PEM_NORM_LINEAR) PEM_SVD_RLAUNCH(PEM_NORM_LINEAR);
     else PEM_SVD_RLAUNCH(PEM_NORM_NONE);
 #undef PEM_SVD_RLAUNCH
+#undef PEM_SVD_RLAUNCH2
     HIP_TRY(hipGetLastError());
     return PEM_OK;
 }
