@@ -412,9 +412,17 @@ int check_args(const char* who, size_t n, int dof, int r, int mode, const void* 
     return PEM_OK;
 }
 
+// The smallest persistent grid that needs as many rounds as `cap` workgroups would: every round full (the last round of a
+// grid of `cap` costs a full round however few of its waves have a tile; pem_kernels.hip fast_grid)
+size_t balanced_blocks(size_t need, size_t cap) {
+    if (need <= cap) return need;
+    const size_t rounds = (need + cap - 1) / cap;
+    return (need + rounds - 1) / rounds;
+}
+
 unsigned grid_for(size_t n, int per_cu = 2) {
     size_t tiles = (n + 15) / 16, blocks = (tiles + WAVES - 1) / WAVES;
-    if (blocks > 256 * (size_t)per_cu) blocks = 256 * (size_t)per_cu;     // persistent: LDS admits 1-3 workgroups per CU
+    blocks = balanced_blocks(blocks, 256 * (size_t)per_cu);               // persistent: LDS admits 1-3 workgroups per CU
     return (unsigned)(blocks ? blocks : 1);
 }
 
@@ -433,8 +441,7 @@ int pem_svd_compress_f64_dev(size_t n, int dof, int rank, int norm, double norm_
     const size_t lds = ((size_t)((dof + kg - 1) / kg) * kg * 16 + (size_t)WAVES * ((rows * dof + kg + 1) & ~1) +
                         (norm == PEM_NORM_LOG10 ? (size_t)pem::LOG_TABLE_DOUBLES : 0)) * 8;
     const size_t tiles = (n + rows - 1) / rows;
-    size_t blocks = (tiles + WAVES - 1) / WAVES;
-    if (blocks > 256 * 2) blocks = 256 * 2;
+    size_t blocks = balanced_blocks((tiles + WAVES - 1) / WAVES, 256 * 2);
 #define PEM_SVD_LAUNCH(ROWS_, UN_, RT_, MODE_)                                                                            \
     do {                                                                                                             \
         static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(svd_compress_kernel<ROWS_, UN_, RT_, MODE_>), \
@@ -462,7 +469,7 @@ int pem_svd_compress_f64_dev(size_t n, int dof, int rank, int norm, double norm_
         size_t dblocks = ((n + 15) / 16 + WAVES - 1) / WAVES;
         static const bool breg = getenv("PEM_SVD_BREG") ? atoi(getenv("PEM_SVD_BREG")) != 0 : true;
         const size_t per_cu = breg ? 3 : 4;           // persistent: workgroups (of four waves) resident per CU, by registers
-        if (dblocks > 256 * per_cu) dblocks = 256 * per_cu;
+        dblocks = balanced_blocks(dblocks, 256 * per_cu);
         hipStream_t st = static_cast<hipStream_t>(stream);
 #define PEM_SVD_DIRECT(MODE_)                                                                                                   \
     do {                                                                                                                        \
