@@ -1264,6 +1264,22 @@ using pem::check_device;
 using pem::fail;
 
 // persistent grid of the fast kernel: workgroups of WPB waves, `per_cu` of them resident on every CU
+// Balanced rounds: a persistent wave takes tiles me, me + nwaves, ...; with the largest grid that fits, a 1.25e6-sample shard is
+// 9.54 tiles per wave -- ten rounds, the last one 54 % full and as long as a full one (a tile's duration is latency, not
+// bandwidth: tools/tail_probe.py).  The smallest grid with the same number of rounds fills every round instead.
+// Only where that costs little occupancy (>= 90 % of the slots stay in use): with two or three rounds the balanced grid is much
+// smaller than the full one and the kernel loses more to the missing parallelism than it gains at the tail (plume_radii_kernel,
+// 1e5 samples x 25 radii, 1.2 rounds: 560 us with the full grid, 655 us balanced; profiles/reconstruct_balanced_r02z.txt).
+// PEM_BALANCED_GRID=0 restores the full grid everywhere.
+size_t balanced_grid(size_t need, size_t cap) {
+    static const bool balanced = getenv("PEM_BALANCED_GRID") ? atoi(getenv("PEM_BALANCED_GRID")) != 0 : true;
+    if (need <= cap) return need;
+    if (!balanced || cap == 0) return cap;
+    const size_t rounds = (need + cap - 1) / cap;
+    const size_t g = (need + rounds - 1) / rounds;
+    return 10 * g >= 9 * cap ? g : cap;
+}
+
 int fast_grid(long long per_cu, long long ntiles, unsigned* grid) {
     static int cus[64] = {0};
     int dev = 0;
@@ -1278,14 +1294,7 @@ int fast_grid(long long per_cu, long long ntiles, unsigned* grid) {
     long long g = (long long)cus[dev] * per_cu;
     const long long need = (ntiles + WPB - 1) / WPB;
     if (g > need) g = need;
-    // Balanced rounds: a persistent wave takes tiles me, me + nwaves, ...; with the full grid a 1.25e6-sample shard is 9.54 tiles
-    // per wave -- ten rounds, the last one 54 % full and as long as a full one (a tile's duration is latency, not bandwidth:
-    // tools/tail_probe.py).  The smallest grid with the same number of rounds fills every round instead.
-    static const bool balanced = getenv("PEM_BALANCED_GRID") ? atoi(getenv("PEM_BALANCED_GRID")) != 0 : true;
-    if (balanced && g > 0) {
-        const long long rounds = (need + g - 1) / g;
-        g = (need + rounds - 1) / rounds;
-    }
+    g = (long long)balanced_grid((size_t)need, (size_t)g);
     *grid = (unsigned)g;
     return PEM_OK;
 }
@@ -1354,7 +1363,7 @@ int launch_rfew(size_t n, hipStream_t st, const PlumeIO& io, const RadiiSmallArg
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const size_t per_cu = (160 * 1024) / lds < 2 ? 1 : 2;          // persistent: workgroups resident per CU
     size_t grid = ((n + WAVE - 1) / WAVE + NW - 1) / NW;
-    if (grid > (size_t)cus * per_cu) grid = (size_t)cus * per_cu;
+    grid = balanced_grid(grid, (size_t)cus * per_cu);
     hipLaunchKernelGGL(plume_rfew_kernel<R>, dim3((unsigned)grid), dim3(WAVE * NW), lds, st, io, ra);
     return PEM_OK;
 }
@@ -1600,7 +1609,7 @@ int pem_plume_f64_dev(size_t n, int n_radii, const double* radii, double torr2pa
         while (ts > 4 && (n + ts - 1) / ts < 256 * 20) ts >>= 1;
         const size_t ntiles = (n + ts - 1) / ts;
         size_t blocks = (ntiles + BLOCK / WAVE - 1) / (BLOCK / WAVE);
-        if (blocks > 256 * 5) blocks = 256 * 5;   // persistent: 31 KB of LDS per workgroup, five per CU
+        blocks = balanced_grid(blocks, 256 * 5);   // persistent: 31 KB of LDS per workgroup, five per CU
         hipLaunchKernelGGL(plume_radii_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, st, io, ra, n_radii, ts);
         HIP_TRY(hipGetLastError());
         return PEM_OK;

@@ -414,10 +414,12 @@ int check_args(const char* who, size_t n, int dof, int r, int mode, const void* 
 
 // The smallest persistent grid that needs as many rounds as `cap` workgroups would: every round full (the last round of a
 // grid of `cap` costs a full round however few of its waves have a tile; pem_kernels.hip fast_grid)
+// -- where that keeps >= 90 % of the slots in use (with two or three rounds the missing parallelism costs more).
 size_t balanced_blocks(size_t need, size_t cap) {
     if (need <= cap) return need;
     const size_t rounds = (need + cap - 1) / cap;
-    return (need + rounds - 1) / rounds;
+    const size_t g = (need + rounds - 1) / rounds;
+    return 10 * g >= 9 * cap ? g : cap;
 }
 
 unsigned grid_for(size_t n, int per_cu = 2) {
