@@ -140,7 +140,7 @@ __global__ __launch_bounds__(BLOCK) void sparse_predict_kernel(long long n, int 
                                                                const double* __restrict__ coef,
                                                                const double* __restrict__ values, int n_out_arg,
                                                                const double* __restrict__ t, size_t ld,
-                                                               double* __restrict__ out, size_t ld_out) {
+                                                               double* __restrict__ out, size_t ld_out, int per_grid) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* basis = lds;                                    // [2 outer dims][MAXM][BLOCK]
     double* coord = lds + 2 * MAXM * BLOCK;                 // [n_dim][BLOCK]
@@ -178,7 +178,17 @@ __global__ __launch_bounds__(BLOCK) void sparse_predict_kernel(long long n, int 
             else if (m[2] == 5) contract_grid<NOUT, EXACT, 5>(m[0], m[1], b0, b1, t2, val, n_out, c, acc);
             else if (m[2] == 9) contract_grid<NOUT, EXACT, 9>(m[0], m[1], b0, b1, t2, val, n_out, c, acc);
             else contract_grid<NOUT, EXACT, 1>(m[0], m[1], b0, b1, t2, val, n_out, c, acc);     // the constant grid (beta = 0)
+            if (per_grid) {      // every grid's own (coefficient-weighted) interpolant: out[bi][o][i]
+                if (i0 + tid < n) {
+#pragma unroll
+                    for (int o = 0; o < NOUT; ++o)
+                        if (EXACT || o < n_out) out[((size_t)bi * n_out + o) * ld_out + i] = acc[o];
+                }
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) acc[o] = 0.0;
+            }
         }
+        if (per_grid) continue;
         if (i0 + tid < n) {
 #pragma unroll
             for (int o = 0; o < NOUT; ++o)
@@ -189,7 +199,7 @@ __global__ __launch_bounds__(BLOCK) void sparse_predict_kernel(long long n, int 
 
 template <int NOUT, bool EXACT>
 void launch_predict(size_t n, int n_dim, int n_beta, const int32_t* index, const double* coef, const double* values, int n_out,
-                    const double* t, size_t ld, double* out, size_t ld_out, hipStream_t st) {
+                    const double* t, size_t ld, double* out, size_t ld_out, int per_grid, hipStream_t st) {
     size_t blocks = (n + BLOCK - 1) / BLOCK;
     if (blocks > 256 * 8) blocks = 256 * 8;
     const size_t lds = (size_t)(2 * MAXM + n_dim) * BLOCK * sizeof(double);    // <= 100 KB at PEM_SURR_MAX_DIM
@@ -199,23 +209,24 @@ void launch_predict(size_t n, int n_dim, int n_beta, const int32_t* index, const
         (void)attr;      // a refusal shows as a launch error below
     }
     hipLaunchKernelGGL((sparse_predict_kernel<NOUT, EXACT>), dim3((unsigned)blocks), dim3(BLOCK), lds, st, (long long)n, n_dim, n_beta,
-                       index, coef, values, n_out, t, ld, out, ld_out);
+                       index, coef, values, n_out, t, ld, out, ld_out, per_grid);
 }
 
 }  // namespace
 
-extern "C" int pem_sparse_predict_f64_dev(size_t n, int n_dim, int n_beta, const int32_t* index, const double* coef,
-                                          const double* values, int n_out, const double* t, size_t ld, double* out,
-                                          size_t ld_out, pem_stream_t stream) {
+namespace {
+
+int sparse_predict(const char* who, size_t n, int n_dim, int n_beta, const int32_t* index, const double* coef, const double* values,
+                   int n_out, const double* t, size_t ld, double* out, size_t ld_out, int per_grid, pem_stream_t stream) {
     if (n_dim < 1 || n_beta < 1 || n_out < 1 || n_out > 16)
-        return pem::fail(PEM_ERR_INVALID_ARG, "pem_sparse_predict: need n_dim, n_beta >= 1 and 1 <= n_out <= 16");
+        return pem::fail(PEM_ERR_INVALID_ARG, "%s: need n_dim, n_beta >= 1 and 1 <= n_out <= 16", who);
     if (n == 0) return PEM_OK;
-    if (!index || !coef || !values || !t || !out) return pem::fail(PEM_ERR_INVALID_ARG, "pem_sparse_predict: NULL array");
-    if (ld < n || ld_out < n) return pem::fail(PEM_ERR_INVALID_ARG, "pem_sparse_predict: leading dimension smaller than n");
+    if (!index || !coef || !values || !t || !out) return pem::fail(PEM_ERR_INVALID_ARG, "%s: NULL array", who);
+    if (ld < n || ld_out < n) return pem::fail(PEM_ERR_INVALID_ARG, "%s: leading dimension smaller than n", who);
+    if (n_dim > PEM_SURR_MAX_DIM) return pem::fail(PEM_ERR_INVALID_ARG, "%s: n_dim <= %d", who, PEM_SURR_MAX_DIM);
     if (int rc = pem::check_device()) return rc;
-    if (n_dim > PEM_SURR_MAX_DIM) return pem::fail(PEM_ERR_INVALID_ARG, "pem_sparse_predict: n_dim <= %d", PEM_SURR_MAX_DIM);
     hipStream_t st = static_cast<hipStream_t>(stream);
-#define PEM_PREDICT(NOUT_, EXACT_) launch_predict<NOUT_, EXACT_>(n, n_dim, n_beta, index, coef, values, n_out, t, ld, out, ld_out, st)
+#define PEM_PREDICT(NOUT_, EXACT_) launch_predict<NOUT_, EXACT_>(n, n_dim, n_beta, index, coef, values, n_out, t, ld, out, ld_out, per_grid, st)
     switch (n_out) {
         case 1: PEM_PREDICT(1, true); break;
         case 2: PEM_PREDICT(2, true); break;
@@ -229,3 +240,19 @@ extern "C" int pem_sparse_predict_f64_dev(size_t n, int n_dim, int n_beta, const
     HIP_TRY(hipGetLastError());
     return PEM_OK;
 }
+
+}  // namespace
+
+extern "C" {
+
+int pem_sparse_predict_f64_dev(size_t n, int n_dim, int n_beta, const int32_t* index, const double* coef, const double* values,
+                               int n_out, const double* t, size_t ld, double* out, size_t ld_out, pem_stream_t stream) {
+    return sparse_predict("pem_sparse_predict", n, n_dim, n_beta, index, coef, values, n_out, t, ld, out, ld_out, 0, stream);
+}
+
+int pem_sparse_grid_values_f64_dev(size_t n, int n_dim, int n_beta, const int32_t* index, const double* coef, const double* values,
+                                   int n_out, const double* t, size_t ld, double* out, size_t ld_out, pem_stream_t stream) {
+    return sparse_predict("pem_sparse_grid_values", n, n_dim, n_beta, index, coef, values, n_out, t, ld, out, ld_out, 1, stream);
+}
+
+}  // extern "C"

@@ -78,11 +78,14 @@ class SparseGridSurrogate:
         axes = [nodes(l) for l in beta]
         return np.array(list(itertools.product(*axes)), dtype=np.float64).T.reshape(self.D, -1)     # [D][prod m]
 
-    def _ensure_values(self, beta):
-        if beta in self.values:
+    def _ensure_values(self, *betas):
+        """True-model values at the grid nodes of the multi-indices that have none yet: ONE coupled launch for all of them."""
+        new = [b for b in dict.fromkeys(betas) if b not in self.values]
+        if not new:
             return
         import torch
-        t = self._grid(beta)
+        grids = [self._grid(b) for b in new]
+        t = np.concatenate(grids, axis=1)
         x = self.to_physical(t)
         n = t.shape[1]
         batch = CoupledBatch(n, device=self.device, profile=False)
@@ -90,9 +93,12 @@ class SparseGridSurrogate:
         full.update(x)
         batch.set_inputs(full)
         batch.run()
-        torch.cuda.synchronize(self.device)
         o = batch.outputs()
-        self.values[beta] = np.stack([o[k].cpu().numpy() for k in self.qoi], axis=1)
+        y = torch.stack([o[k] for k in self.qoi], dim=1).cpu().numpy()          # (the copy synchronises)
+        off = 0
+        for b, g in zip(new, grids):
+            self.values[b] = y[off:off + g.shape[1]]
+            off += g.shape[1]
         self.model_evals += n
 
     # ---- index-set bookkeeping (shape of monte_carlo.py:714-747) ------------------------------------------------------
@@ -135,9 +141,29 @@ class SparseGridSurrogate:
         return coefs
 
     # ---- device tables + predict ------------------------------------------------------------------------------------
-    def _build_tables(self, index_set):
+    @staticmethod
+    def combination_delta(index_set, cand):
+        """Change of the combination coefficients when `cand` joins `index_set`: every term of c_beta's sum that has
+        beta + e = cand, i.e. {cand - e: (-1)^|e|} over e in {0,1}^D with cand - e in the set (or e = 0).  Equal to
+        combination_coefficients(index_set + [cand]) - combination_coefficients(index_set); 2^(active dims of cand) terms."""
+        members = set(index_set)
+        active = [d for d in range(len(cand)) if cand[d] > 0]
+        delta = {}
+        for r in range(len(active) + 1):
+            for dims in itertools.combinations(active, r):
+                b = list(cand)
+                for d in dims:
+                    b[d] -= 1
+                b = tuple(b)
+                if r == 0 or b in members:
+                    delta[b] = (-1) ** r
+        return delta
+
+    def _build_tables(self, index_set, unit_coefficients: bool = False):
+        """Device tables of the kernel for `index_set`: the grids with a non-zero combination coefficient, or -- with
+        `unit_coefficients` -- every grid with coefficient 1 (for `grid_values`)."""
         import torch
-        coefs = self.combination_coefficients(index_set)
+        coefs = {b: 1 for b in index_set} if unit_coefficients else self.combination_coefficients(index_set)
         used = [b for b in index_set if coefs[b] != 0]
         idx = np.zeros((len(used), 2 + 2 * MAX_ACTIVE), dtype=np.int32)
         vals, off = [], 0
@@ -176,6 +202,21 @@ class SparseGridSurrogate:
                 C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
         return out
 
+    def grid_values(self, t, index_set):
+        """[len(index_set)][n_out][n]: the interpolant of every grid of `index_set` at the points t ([D][n] CUDA tensor), one
+        launch (`pem_sparse_grid_values_f64_dev`).  A prediction with combination coefficients c is c @ grid_values."""
+        import torch
+        idx, coef, vals, nb = self._build_tables(index_set, unit_coefficients=True)
+        t = t.to(device=self.device, dtype=torch.float64).contiguous()
+        n = t.shape[1]
+        out = torch.empty((nb, len(self.qoi), n), dtype=torch.float64, device=self.device)
+        p = lambda x: C.c_void_p(x.data_ptr())                                                             # noqa: E731
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().pem_sparse_grid_values_f64_dev(
+                n, self.D, nb, p(idx), p(coef), p(vals), len(self.qoi), p(t), t.stride(0), p(out), out.stride(1),
+                C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        return out
+
     # ---- adaptive refinement -------------------------------------------------------------------------------------------
     def refine(self, max_iter: int = 10, num_refine: int = 1000, seed: int = 0, max_tol: float = 0.0):
         """Activate, `max_iter` times, the candidate with the largest error indicator.  Returns the training history
@@ -188,15 +229,27 @@ class SparseGridSurrogate:
             if not self.candidates:
                 break
             t = torch.rand((self.D, num_refine), dtype=torch.float64, device=self.device, generator=g) * 2 - 1
-            base = self.predict(t)
+            cands = list(self.candidates)
+            self._ensure_values(*cands)
+            # A prediction is linear in the combination coefficients: ONE launch gives every grid's interpolant at the
+            # points (active grids and candidates alike), and the current surrogate plus every trial index set is a row
+            # of a small matrix product -- instead of one table upload and one launch per candidate.
+            every = self.index_set + cands
+            col = {b: i for i, b in enumerate(every)}
+            cmat = np.zeros((1 + len(cands), len(every)))
+            for b, c in self.combination_coefficients(self.index_set).items():
+                cmat[0, col[b]] = c
+            for r, cand in enumerate(cands):
+                cmat[1 + r] = cmat[0]
+                for b, c in self.combination_delta(self.index_set, cand).items():
+                    cmat[1 + r, col[b]] += c
+            gv = self.grid_values(t, every)                                                     # [B][n_out][n]
+            f = (torch.from_numpy(cmat).to(self.device) @ gv.reshape(len(every), -1)).reshape(1 + len(cands), len(self.qoi), -1)
+            base = f[0]
             scale = (base.max(dim=1).values - base.min(dim=1).values).clamp_min(1e-12)
-            best, best_err = None, -1.0
-            for cand in list(self.candidates):
-                self._ensure_values(cand)
-                trial = self.predict(t, index_set=self.index_set + [cand])
-                err = float(((trial - base).abs().mean(dim=1) / scale).max())
-                if err > best_err:
-                    best, best_err = cand, err
+            errs = ((f[1:] - base).abs().mean(dim=2) / scale).max(dim=1).values.cpu().numpy()
+            k = int(np.argmax(errs))                                                            # first of equal maxima, as before
+            best, best_err = cands[k], float(errs[k])
             self._activate(best)
             history.append((best, best_err, self.model_evals))
             if best_err < max_tol:

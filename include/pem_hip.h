@@ -249,6 +249,12 @@ int pem_svd_reconstruct_f64_dev(size_t n, int dof, int rank, int norm, double no
 int pem_sparse_predict_f64_dev(size_t n, int n_dim, int n_beta, const int32_t* index, const double* coef,
                                const double* values, int n_out, const double* t, size_t ld, double* out,
                                size_t ld_out, pem_stream_t stream);
+/* The same tables, every grid on its own: out[b][o][i] = coef[b] * (the interpolant of grid b at point i), out: [n_beta][n_out]
+ * [ld_out].  The adaptive refinement scores all its candidate index sets from ONE such launch -- a prediction is linear in the
+ * combination coefficients, so each trial is a [n_beta] x [n_beta][n_out n] product of these values (surrogate.py refine). */
+int pem_sparse_grid_values_f64_dev(size_t n, int n_dim, int n_beta, const int32_t* index, const double* coef,
+                                   const double* values, int n_out, const double* t, size_t ld, double* out,
+                                   size_t ld_out, pem_stream_t stream);
 
 /* ---- fused Monte-Carlo evaluation -----------------------------------------------------------------
  * sample_inputs + predict of scripts/gen_data.py:238-239 in ONE launch: the 15 coupled inputs of global samples

@@ -22,6 +22,22 @@ def test_combination_coefficients_identities():
     assert SparseGridSurrogate.combination_coefficients([(0, 0), (1, 0), (2, 0)]) == {(0, 0): 0, (1, 0): 0, (2, 0): 1}
 
 
+def test_combination_delta_equals_the_difference_of_coefficient_sets():
+    rng = np.random.default_rng(0)
+    D = 4
+    for _ in range(40):
+        I = [(0,) * D]                                    # a random downward-closed set, grown one admissible index at a time
+        for _ in range(rng.integers(1, 25)):
+            cands = {b[:d] + (b[d] + 1,) + b[d + 1:] for b in I for d in range(D)} - set(I)
+            cands = [c for c in cands if all(c[:d] + (c[d] - 1,) + c[d + 1:] in I for d in range(D) if c[d] > 0)]
+            cand = cands[rng.integers(len(cands))]
+            before = SparseGridSurrogate.combination_coefficients(I)
+            after = SparseGridSurrogate.combination_coefficients(I + [cand])
+            delta = SparseGridSurrogate.combination_delta(I, cand)
+            assert {b: after[b] - before.get(b, 0) for b in after if after[b] - before.get(b, 0) != 0} == delta
+            I.append(cand)
+
+
 FIXED = {'P_b': 1e-5, 'V_a': 300.0, 'mdot_a': 5e-6, 'a_1': 0.01, 'sigma_cex': 55e-20, 'c4': 1e20, 'c5': 1e16}
 VARIED = ('T_e', 'V_vac', 'Pstar', 'P_T', 'c0', 'c1', 'c2', 'c3')
 
@@ -133,3 +149,24 @@ def test_predict_kernel_synthetic_tables_all_output_widths(n_out):
     want = snp.predict(used, coefs, values, t)
     assert np.max(np.abs(got[:, :n] - want) / np.abs(want).max(axis=1, keepdims=True)) < 1e-12
     assert _lib.load().pem_sparse_predict_f64_dev(n, 33, len(used), p(d_idx), p(d_coef), p(d_val), n_out, p(d_t), n, p(out), n + 7, None) != 0
+
+
+@pytest.mark.gpu
+def test_grid_values_times_coefficients_is_the_prediction():
+    """pem_sparse_grid_values_f64_dev: every grid's interpolant on its own; a prediction is the combination-coefficient row times
+    those values -- what `refine` builds all its trial index sets from."""
+    import torch
+    s = SparseGridSurrogate(VARIED, FIXED)
+    s.refine(max_iter=8, num_refine=200, seed=5)
+    I = list(s.index_set)
+    t = torch.from_numpy(np.random.default_rng(2).uniform(-1, 1, (len(VARIED), 777))).cuda()
+    gv = s.grid_values(t, I)
+    assert gv.shape == (len(I), len(s.qoi), 777)
+    c = s.combination_coefficients(I)
+    row = torch.tensor([float(c[b]) for b in I], dtype=torch.float64, device='cuda')
+    want = s.predict(t)
+    got = (row @ gv.reshape(len(I), -1)).reshape(len(s.qoi), -1)
+    assert float(((got - want).abs() / want.abs().max(dim=1, keepdim=True).values).max()) < 1e-12
+    # the constant grid (beta = 0) returns the model value at the centre of the box for every point
+    zero = I.index((0,) * len(VARIED))
+    assert torch.equal(gv[zero], torch.from_numpy(s.values[(0,) * len(VARIED)][0]).cuda()[:, None].expand(-1, 777))
