@@ -1280,7 +1280,7 @@ size_t balanced_grid(size_t need, size_t cap) {
     return 10 * g >= 9 * cap ? g : cap;
 }
 
-int fast_grid(long long per_cu, long long ntiles, unsigned* grid) {
+int fast_grid(long long per_cu, long long ntiles, bool memory_bound, unsigned* grid) {
     static int cus[64] = {0};
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
@@ -1294,7 +1294,9 @@ int fast_grid(long long per_cu, long long ntiles, unsigned* grid) {
     long long g = (long long)cus[dev] * per_cu;
     const long long need = (ntiles + WPB - 1) / WPB;
     if (g > need) g = need;
-    g = (long long)balanced_grid((size_t)need, (size_t)g);
+    // (the modes bound by instruction issue want every slot: balanced, the reduced-QoI launch takes 45.3 instead of 44.4 us and
+    // the fused Monte-Carlo one 88 instead of 82 us; tools/grid_ab_probe.py)
+    if (memory_bound) g = (long long)balanced_grid((size_t)need, (size_t)g);
     *grid = (unsigned)g;
     return PEM_OK;
 }
@@ -1332,7 +1334,7 @@ int launch_r1(const PlumeIO& io, const CoupledIO& cio, hipStream_t st, const McD
     const int cap = (JMODE == 0 ? 12 : 8) / WPB;
     if (cached_per_cu > by_regs) cached_per_cu = by_regs;
     if (cached_per_cu > cap) cached_per_cu = cap;
-    if (int rc = fast_grid(cached_per_cu, ntiles, &grid)) return rc;
+    if (int rc = fast_grid(cached_per_cu, ntiles, JMODE == 1 || JMODE == 2, &grid)) return rc;
     if constexpr (MC) hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * WPB), lds, st, io, cio, ntiles, mc);
     else hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * WPB), lds, st, io, cio, ntiles, NoDesign{});
     HIP_TRY(hipGetLastError());
