@@ -254,7 +254,13 @@ def main():
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
         if args.dist_backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_dev))
+            # RCCL's kernels on a high-priority stream: the all-gather of piece k has to get onto the chip beside the
+            # persistent evaluation kernel of piece k + 1 (which also leaves a few workgroup slots free: balanced rounds)
+            try:
+                opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+                dist.init_process_group('nccl', device_id=torch.device('cuda', local_dev), pg_options=opts)
+            except (AttributeError, TypeError):
+                dist.init_process_group('nccl', device_id=torch.device('cuda', local_dev))
         else:
             dist.init_process_group(args.dist_backend)
 
