@@ -1,0 +1,717 @@
+// pem_quantile.hip -- per-column order statistics over the SAMPLE axis of a row-major [n][m] array (gfx950): the percentiles
+// behind the NaN / interquartile-range masks of scripts/gen_data.py:125-174 (`np.percentile(arr, 25 | 75, axis=0)`) and the
+// 5 / 50 / 95 % bands of scripts/pem_v0/monte_carlo.py:363-658, at forward-UQ sizes: 1e7 samples x 91 angles is 7.3 GB, and
+// a sort-based quantile (torch.quantile) refuses more than 2^24 values per column and sorts everything to pick two of them.
+//
+// Exact selection, not an estimate: the caller (drivers.column_percentiles) hands over the RANKS numpy's method 'linear' reads
+// -- floor((n - 1) q) and the one above -- with its interpolation weight, this file returns x_(rank) for every column and
+// applies numpy's _lerp, so the result equals np.percentile bit for bit (NaN in a column -> NaN, as there).
+//
+// Four streaming passes over the data, each coalesced (a lane owns fixed columns: consecutive lanes read consecutive
+// addresses of a row, or of several short rows) and each bound by HBM:
+//   1. min / max per column of the order-preserving integer image of the values (and whether a NaN is present);
+//   2. a histogram per column over [min, max] (BINS1 bins, counted in LDS, merged with one atomic per bin and workgroup);
+//      -> for every wanted rank: the bin that holds it and its rank inside the bin;
+//   3. a second histogram per wanted rank inside its bin (BINS2 sub-bins);
+//      -> the sub-bin and the rank inside it: by now 1 / (BINS1 BINS2) of a column's values are left per rank;
+//   4. those values are copied out (exact sizes are known from pass 3; ranks that share a sub-bin share a list).
+// Then one workgroup per list sorts it in LDS and reads the ranks off; a list too long for LDS -- heavy ties, e.g. the
+// 1e-20 profile of invalid samples -- is narrowed by further histograms over the list itself until it fits or is one value.
+// Monotone binning is all the method needs: bin(k) = floor((k - lo) * BINS / (hi - lo + 1)) in double arithmetic never
+// decreases with the key, so everything in a lower bin is <= everything in a higher one and equal keys share a bin.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <mutex>
+
+#include "pem_common.h"
+#include "pem_hip.h"
+
+namespace {
+
+typedef unsigned long long u64;
+constexpr int QBLOCK = 512;               // two waves per SIMD share one workgroup's LDS histogram
+constexpr int QWAVES = QBLOCK / 64;
+constexpr int LDS_WORDS = 36864;          // 144 KB of 32-bit counters per workgroup
+constexpr int SORT_CAP = 4096;            // keys a workgroup sorts in LDS (32 KB)
+constexpr int MAX_NC = 4;                 // columns per lane: m <= 256
+constexpr int UNROLL = 8;                 // row groups a wave requests before it consumes any (loads in flight per lane: UNROLL x NC)
+static_assert(PEM_QUANTILE_MAX_Q == 3, "hist2_kernel / compact_kernel are instantiated for 2, 4 and 6 ranks per column");
+
+// order-preserving image of a double (NaN excluded by the callers): negative values reversed, sign bit flipped
+__device__ __forceinline__ u64 key_of(double x) {
+    const u64 b = (u64)__double_as_longlong(x);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double value_of(u64 k) {
+    const u64 b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+__device__ __forceinline__ int bin_of(u64 k, u64 lo, double inv, int bins) {
+    const int b = (int)((double)(k - lo) * inv);
+    return b < bins - 1 ? b : bins - 1;
+}
+// the sub-bin inside bin b of the same map (fractional part of the scaled offset)
+__device__ __forceinline__ int subbin_of(u64 k, u64 lo, double inv, int b, int bins2) {
+    const double f = (double)(k - lo) * inv - (double)b;
+    const int s = (int)(f * (double)bins2);
+    return s < 0 ? 0 : (s < bins2 - 1 ? s : bins2 - 1);
+}
+
+struct Column {          // per column
+    u64 kmin, kmax;
+    int has_nan, pad;
+    double inv1;         // BINS1 / (kmax - kmin + 1)
+};
+struct Target {          // per (column, wanted rank)
+    u64 rank;            // in: 0-based rank in the column; then the rank inside the current bin / list
+    u64 count;           // values in the target's sub-bin (= length of its list)
+    u64 offset;          // start of its list in the candidate buffer
+    u64 cursor;          // append position during pass 4
+    u64 answer;          // the key x_(rank)
+    int bin1, bin2;
+    int owner;           // index of the target (of this column) whose list this one shares, or its own index
+    int done;            // answer already known (constant column)
+};
+
+// lane -> the columns it owns.  m <= 64: a wave instruction covers rpw = 64 / m whole rows (lane = row-in-group * m + column);
+// m > 64: one row per wave instruction and chunk, column = lane + 64 chunk.
+struct Lanes {
+    int rpw, active, col0, rsub;
+    __device__ Lanes(int m, int lane) {
+        if (m <= 64) {
+            rpw = 64 / m;
+            active = lane < rpw * m;
+            col0 = lane % m;
+            rsub = lane / m;
+        } else {
+            rpw = 1;
+            active = 1;
+            col0 = lane;
+            rsub = 0;
+        }
+    }
+};
+
+// Every value of the array once: f(j, column, x) for the lane's j-th column.  A wave takes UNROLL consecutive row groups at a
+// time and requests all their values before it consumes the first (with one workgroup of 144 KB of LDS per CU the memory
+// latency has to be covered inside the wave).
+template <int NC, class F>
+__device__ __forceinline__ void stream_values(long long n, int m, size_t ld, const double* __restrict__ data, const Lanes& L, F f) {
+    const long long wave = (long long)blockIdx.x * QWAVES + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * QWAVES;
+    const long long groups = (n + L.rpw - 1) / L.rpw;
+    for (long long g0 = wave * UNROLL; g0 < groups; g0 += nwaves * UNROLL) {
+        double x[UNROLL][NC];
+        bool ok[UNROLL][NC];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const long long row = (g0 + u) * L.rpw + L.rsub;
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                const int c = L.col0 + 64 * j;
+                ok[u][j] = L.active && c < m && row < n;
+                x[u][j] = ok[u][j] ? data[(size_t)row * ld + c] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+#pragma unroll
+            for (int j = 0; j < NC; ++j)
+                if (ok[u][j]) f(j, L.col0 + 64 * j, x[u][j]);
+        }
+    }
+}
+
+struct Wanted {          // the call's quantiles travel in the kernel arguments (nq <= 3): no host-to-device copy to wait for
+    u64 prev[PEM_QUANTILE_MAX_Q], next[PEM_QUANTILE_MAX_Q];
+    double gamma[PEM_QUANTILE_MAX_Q];
+};
+
+__global__ void init_columns_kernel(Column* col, Target* tg, int m, int nq, Wanted w) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < m) {
+        col[c].kmin = ~0ull;
+        col[c].kmax = 0ull;
+        col[c].has_nan = 0;
+        for (int q = 0; q < nq; ++q) {
+            Target t = {};
+            t.rank = w.prev[q];
+            tg[c * 2 * nq + 2 * q] = t;
+            t.rank = w.next[q];
+            tg[c * 2 * nq + 2 * q + 1] = t;
+        }
+    }
+}
+
+// ---- pass 1: min / max / NaN per column ------------------------------------------------------------------------------
+template <int NC>
+__global__ __launch_bounds__(QBLOCK) void minmax_kernel(long long n, int m, size_t ld, const double* __restrict__ data, Column* __restrict__ col) {
+    const Lanes L(m, threadIdx.x & 63);
+    u64 lo[NC], hi[NC];
+    int nan[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        lo[j] = ~0ull;
+        hi[j] = 0ull;
+        nan[j] = 0;
+    }
+    stream_values<NC>(n, m, ld, data, L, [&](int j, int, double x) {
+        if (x != x) nan[j] = 1;
+        else {
+            const u64 k = key_of(x);
+            lo[j] = k < lo[j] ? k : lo[j];
+            hi[j] = k > hi[j] ? k : hi[j];
+        }
+    });
+    // workgroup first (LDS), then one global atomic per column and workgroup: with few columns every lane of the grid owns
+    // the same ones, and 2.6e5 lanes queueing on one address cost 7 ms
+    __shared__ u64 s_lo[64 * MAX_NC], s_hi[64 * MAX_NC];
+    __shared__ int s_nan[64 * MAX_NC];
+    for (int c = threadIdx.x; c < m; c += QBLOCK) {
+        s_lo[c] = ~0ull;
+        s_hi[c] = 0ull;
+        s_nan[c] = 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const int c = L.col0 + 64 * j;
+        if (L.active && c < m) {
+            if (lo[j] <= hi[j]) {
+                atomicMin(&s_lo[c], lo[j]);
+                atomicMax(&s_hi[c], hi[j]);
+            }
+            if (nan[j]) atomicOr(&s_nan[c], 1);
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < m; c += QBLOCK) {
+        if (s_lo[c] <= s_hi[c]) {
+            atomicMin(&col[c].kmin, s_lo[c]);
+            atomicMax(&col[c].kmax, s_hi[c]);
+        }
+        if (s_nan[c]) atomicOr(&col[c].has_nan, 1);
+    }
+}
+
+__global__ void scale_columns_kernel(Column* col, int m, int bins1) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < m) {
+        const Column k = col[c];
+        col[c].inv1 = k.kmax >= k.kmin ? (double)bins1 / ((double)(k.kmax - k.kmin) + 1.0) : 0.0;
+    }
+}
+
+// ---- pass 2: histogram per column ------------------------------------------------------------------------------------
+template <int NC>
+__global__ __launch_bounds__(QBLOCK) void hist1_kernel(long long n, int m, size_t ld, const double* __restrict__ data, const Column* __restrict__ col,
+                                                        int bins1, unsigned* __restrict__ hist1) {
+    extern __shared__ unsigned lds_hist[];
+    for (int i = threadIdx.x; i < m * bins1; i += QBLOCK) lds_hist[i] = 0;
+    __syncthreads();
+    const Lanes L(m, threadIdx.x & 63);
+    u64 klo[NC];
+    double inv[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const int c = L.col0 + 64 * j;
+        const bool on = L.active && c < m;
+        klo[j] = on ? col[c].kmin : 0;
+        inv[j] = on ? col[c].inv1 : 0.0;
+    }
+    stream_values<NC>(n, m, ld, data, L, [&](int j, int c, double x) {
+        if (x == x) atomicAdd(&lds_hist[c * bins1 + bin_of(key_of(x), klo[j], inv[j], bins1)], 1u);
+    });
+    __syncthreads();
+    for (int i = threadIdx.x; i < m * bins1; i += QBLOCK) {
+        const unsigned v = lds_hist[i];
+        if (v) atomicAdd(&hist1[i], v);
+    }
+}
+
+// The bin of a histogram that holds `rank` (0-based among the counted values), searched by one WAVE: every lane sums a
+// chunk of the bins, the lanes' sums are scanned with shuffles, the lane whose chunk holds the rank walks it.  (One thread
+// walking 4096 bins in global memory took 0.4-0.9 ms per launch -- more than the four passes over a scalar QoI's data.)
+struct Found {
+    int bin;
+    u64 before;      // values in the bins below
+    unsigned count;  // values in the bin
+};
+__device__ __forceinline__ Found find_bin(const unsigned* __restrict__ h, int bins, u64 rank, int lane) {
+    const int per = (bins + 63) / 64, b0 = lane * per;
+    u64 mine = 0;
+    for (int b = b0; b < b0 + per && b < bins; ++b) mine += h[b];
+    u64 incl = mine;
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1) {
+        const u64 up = __shfl_up(incl, sh);
+        if (lane >= sh) incl += up;
+    }
+    const unsigned long long holds = __ballot(incl > rank);
+    const int src = holds ? __builtin_ctzll(holds) : 63;
+    u64 cum = __shfl(incl - mine, src);
+    const int s0 = src * per;
+    int bin = s0;
+    unsigned cnt = 0;
+    if (lane == src) {
+        int last = s0 + per < bins ? s0 + per : bins;
+        for (; bin < last - 1; ++bin) {
+            if (cum + h[bin] > rank) break;
+            cum += h[bin];
+        }
+        if (bin > bins - 1) bin = bins - 1;
+        cnt = h[bin];
+    }
+    Found f;
+    f.bin = __shfl(bin, src);
+    f.before = __shfl(cum, src);
+    f.count = (unsigned)__shfl((int)cnt, src);
+    return f;
+}
+
+// one wave per (column, target): the bin that holds the rank
+__global__ __launch_bounds__(64) void decide1_kernel(int m, int nt, const Column* __restrict__ col, const unsigned* __restrict__ hist1, int bins1,
+                                                      Target* __restrict__ tg) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const int c = i / nt;
+    Target t = tg[i];
+    t.owner = i - c * nt;
+    if (col[c].kmin >= col[c].kmax) {          // a constant column (or one without a finite value: its result is NaN anyway)
+        t.done = 1;
+        t.answer = col[c].kmin;
+        t.bin1 = -1;
+    } else {
+        const Found f = find_bin(hist1 + (size_t)c * bins1, bins1, t.rank, lane);
+        t.bin1 = f.bin;
+        t.rank -= f.before;
+    }
+    if (lane == 0) tg[i] = t;
+}
+
+// ---- pass 3: histogram of every target's bin -----------------------------------------------------------------------------
+template <int NC, int NT>
+__global__ __launch_bounds__(QBLOCK) void hist2_kernel(long long n, int m, size_t ld, const double* __restrict__ data, const Column* __restrict__ col,
+                                                        const Target* __restrict__ tg, int bins1, int bins2,
+                                                        unsigned* __restrict__ hist2) {
+    extern __shared__ unsigned lds_hist[];
+    for (int i = threadIdx.x; i < m * NT * bins2; i += QBLOCK) lds_hist[i] = 0;
+    __syncthreads();
+    const Lanes L(m, threadIdx.x & 63);
+    u64 klo[NC];
+    double inv[NC];
+    int tb[NC][NT];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const int c = L.col0 + 64 * j;
+        const bool on = L.active && c < m;
+        klo[j] = on ? col[c].kmin : 0;
+        inv[j] = on ? col[c].inv1 : 0.0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            // targets of a column often share a bin: each DISTINCT bin is counted once, under the first target that has it
+            int b = on ? tg[c * NT + t].bin1 : -1;
+#pragma unroll
+            for (int u = 0; u < t; ++u)
+                if (tb[j][u] == b || (on && tg[c * NT + u].bin1 == b)) b = -1;
+            tb[j][t] = b;
+        }
+    }
+    stream_values<NC>(n, m, ld, data, L, [&](int j, int c, double x) {
+        if (x == x) {
+            const u64 k = key_of(x);
+            const int b = bin_of(k, klo[j], inv[j], bins1);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (tb[j][t] == b) atomicAdd(&lds_hist[(c * NT + t) * bins2 + subbin_of(k, klo[j], inv[j], b, bins2)], 1u);
+        }
+    });
+    __syncthreads();
+    for (int i = threadIdx.x; i < m * NT * bins2; i += QBLOCK) {
+        const unsigned v = lds_hist[i];
+        if (v) atomicAdd(&hist2[i], v);
+    }
+}
+
+// one wave per (column, target): the sub-bin that holds the rank (the histogram sits under the column's first target with
+// the same bin)
+__global__ __launch_bounds__(64) void decide2_kernel(int nt, const unsigned* __restrict__ hist2, int bins2, Target* __restrict__ tg) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const int c = i / nt, t = i - c * nt;
+    Target T = tg[i];
+    if (T.done) return;
+    int first = t;
+    for (int u = t - 1; u >= 0; --u)
+        if (!tg[c * nt + u].done && tg[c * nt + u].bin1 == T.bin1) first = u;
+    const Found f = find_bin(hist2 + (size_t)(c * nt + first) * bins2, bins2, T.rank, lane);
+    T.bin2 = f.bin;
+    T.rank -= f.before;
+    T.count = f.count;
+    if (lane == 0) tg[i] = T;
+}
+
+// ONE workgroup, one thread per column: which targets of a column share a list (same bin and sub-bin), and where the lists
+// start in the candidate buffer (a scan over the columns in LDS)
+__global__ __launch_bounds__(64 * MAX_NC) void layout_kernel(int m, int nt, Target* __restrict__ tg, u64* __restrict__ total) {
+    __shared__ u64 start[64 * MAX_NC + 1];
+    const int c = threadIdx.x;
+    u64 mine = 0;
+    if (c < m) {
+        for (int t = 0; t < nt; ++t) {
+            Target& T = tg[c * nt + t];
+            if (T.done) continue;
+            T.owner = t;
+            for (int u = 0; u < t; ++u) {
+                const Target& U = tg[c * nt + u];
+                if (!U.done && U.bin1 == T.bin1 && U.bin2 == T.bin2) {
+                    T.owner = U.owner;
+                    break;
+                }
+            }
+            if (T.owner == t) mine += T.count;
+        }
+    }
+    start[c + 1] = mine;
+    if (c == 0) start[0] = 0;
+    __syncthreads();
+    if (c == 0) {
+        for (int k = 1; k <= 64 * MAX_NC; ++k) start[k] += start[k - 1];          // 256 additions in LDS
+        total[0] = start[m];
+    }
+    __syncthreads();
+    if (c < m) {
+        u64 off = start[c];
+        for (int t = 0; t < nt; ++t) {
+            Target& T = tg[c * nt + t];
+            if (T.done) continue;
+            if (T.owner == t) {
+                T.offset = off;
+                off += T.count;
+            } else {
+                T.offset = tg[c * nt + T.owner].offset;
+            }
+        }
+    }
+}
+
+// ---- pass 4: copy the candidates out ----------------------------------------------------------------------------------------
+template <int NC, int NT>
+__global__ __launch_bounds__(QBLOCK) void compact_kernel(long long n, int m, size_t ld, const double* __restrict__ data, const Column* __restrict__ col,
+                                                          Target* __restrict__ tg, int bins1, int bins2, u64* __restrict__ cand) {
+    const Lanes L(m, threadIdx.x & 63);
+    u64 klo[NC];
+    double inv[NC];
+    int tb1[NC][NT], tb2[NC][NT];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const int c = L.col0 + 64 * j;
+        const bool on = L.active && c < m;
+        klo[j] = on ? col[c].kmin : 0;
+        inv[j] = on ? col[c].inv1 : 0.0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const bool own = on && !tg[c * NT + t].done && tg[c * NT + t].owner == t;       // only list owners collect
+            tb1[j][t] = own ? tg[c * NT + t].bin1 : -1;
+            tb2[j][t] = own ? tg[c * NT + t].bin2 : -1;
+        }
+    }
+    stream_values<NC>(n, m, ld, data, L, [&](int j, int c, double x) {
+        if (x == x) {
+            const u64 k = key_of(x);
+            const int b = bin_of(k, klo[j], inv[j], bins1);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (tb1[j][t] == b && subbin_of(k, klo[j], inv[j], b, bins2) == tb2[j][t]) {
+                    Target& T = tg[c * NT + t];
+                    cand[T.offset + atomicAdd(&T.cursor, 1ull)] = k;
+                }
+            }
+        }
+    });
+}
+
+// ---- the lists: one workgroup per (column, target) ----------------------------------------------------------------------------
+__device__ void block_sort(u64* s, int np2) {      // bitonic, np2 a power of two <= SORT_CAP, all QBLOCK threads
+    for (int k = 2; k <= np2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < np2; i += QBLOCK) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const u64 a = s[i], b = s[p];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) {
+                        s[i] = b;
+                        s[p] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(QBLOCK) void select_kernel(int nt, Target* __restrict__ tg, const u64* __restrict__ cand) {
+    __shared__ u64 keys[SORT_CAP];
+    __shared__ unsigned hist[1024];
+    __shared__ u64 s_lo, s_hi, s_cnt, s_rank;
+    __shared__ int s_bin;
+    Target& T = tg[blockIdx.x];
+    if (T.done) return;
+    const u64* list = cand + T.offset;
+    const u64 len = T.count;
+    u64 lo = 0, hi = ~0ull, rank = T.rank;
+    for (;;) {
+        // the keys of the list inside [lo, hi]: how many, their smallest and largest
+        if (threadIdx.x == 0) {
+            s_lo = ~0ull;
+            s_hi = 0;
+            s_cnt = 0;
+        }
+        __syncthreads();
+        u64 mn = ~0ull, mx = 0, cnt = 0;
+        for (u64 i = threadIdx.x; i < len; i += QBLOCK) {
+            const u64 k = list[i];
+            if (k >= lo && k <= hi) {
+                mn = k < mn ? k : mn;
+                mx = k > mx ? k : mx;
+                ++cnt;
+            }
+        }
+        if (cnt) {
+            atomicMin(&s_lo, mn);
+            atomicMax(&s_hi, mx);
+            atomicAdd(&s_cnt, cnt);
+        }
+        __syncthreads();
+        lo = s_lo;
+        hi = s_hi;
+        const u64 inside = s_cnt;
+        __syncthreads();
+        if (lo >= hi) {                        // one value left (or, defensively, nothing)
+            if (threadIdx.x == 0) {
+                T.answer = lo;
+                T.done = 1;
+            }
+            return;
+        }
+        if (inside <= SORT_CAP) {
+            int np2 = 1;
+            while (np2 < (int)inside) np2 <<= 1;
+            if (threadIdx.x == 0) s_cnt = 0;
+            for (int i = threadIdx.x; i < np2; i += QBLOCK) keys[i] = ~0ull;
+            __syncthreads();
+            for (u64 i = threadIdx.x; i < len; i += QBLOCK) {
+                const u64 k = list[i];
+                if (k >= lo && k <= hi) keys[atomicAdd(&s_cnt, 1ull)] = k;
+            }
+            __syncthreads();
+            block_sort(keys, np2);
+            if (threadIdx.x == 0) {
+                T.answer = keys[rank < inside ? rank : inside - 1];
+                T.done = 1;
+            }
+            return;
+        }
+        // too long for LDS: 1024-bin histogram over [lo, hi], keep the bin that holds the rank
+        for (int i = threadIdx.x; i < 1024; i += QBLOCK) hist[i] = 0;
+        __syncthreads();
+        const double inv = 1024.0 / ((double)(hi - lo) + 1.0);
+        for (u64 i = threadIdx.x; i < len; i += QBLOCK) {
+            const u64 k = list[i];
+            if (k >= lo && k <= hi) atomicAdd(&hist[bin_of(k, lo, inv, 1024)], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            u64 cum = 0;
+            int b = 0;
+            for (; b < 1023; ++b) {
+                if (cum + hist[b] > rank) break;
+                cum += hist[b];
+            }
+            s_bin = b;
+            s_rank = rank - cum;
+        }
+        __syncthreads();
+        const int keep = s_bin;
+        rank = s_rank;
+        // the keys of that bin form an interval of keys (monotone binning): its ends are found by the next round's min / max
+        if (threadIdx.x == 0) {
+            s_lo = ~0ull;
+            s_hi = 0;
+        }
+        __syncthreads();
+        mn = ~0ull;
+        mx = 0;
+        for (u64 i = threadIdx.x; i < len; i += QBLOCK) {
+            const u64 k = list[i];
+            if (k >= lo && k <= hi && bin_of(k, lo, inv, 1024) == keep) {
+                mn = k < mn ? k : mn;
+                mx = k > mx ? k : mx;
+            }
+        }
+        if (mn <= mx) {
+            atomicMin(&s_lo, mn);
+            atomicMax(&s_hi, mx);
+        }
+        __syncthreads();
+        lo = s_lo;
+        hi = s_hi;
+        __syncthreads();
+    }
+}
+
+// out[q][c] = numpy's _lerp(x_(prev), x_(next), gamma); NaN where the column holds one
+__global__ void finish_kernel(int m, int nq, const Column* __restrict__ col, const Target* __restrict__ tg, Wanted w,
+                              double* __restrict__ out) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m * nq) return;
+    const int q = i / m, c = i - q * m;
+    const double a = value_of(tg[c * 2 * nq + 2 * q].answer), b = value_of(tg[c * 2 * nq + 2 * q + 1].answer), t = w.gamma[q];
+    const double diff = b - a;
+    double r = a + diff * t;
+    if (t >= 0.5) r = b - diff * (1.0 - t);
+    if (col[c].has_nan || col[c].kmin > col[c].kmax) r = __builtin_nan("");
+    out[(size_t)q * m + c] = r;
+}
+
+int pow2_at_most(long long x, int cap) {
+    int p = 1;
+    while (2LL * p <= x && 2 * p <= cap) p <<= 1;
+    return p;
+}
+
+}  // namespace
+
+extern "C" int pem_quantiles_f64_dev(size_t n, int m, const double* data, size_t ld, int nq, const uint64_t* rank_prev, const uint64_t* rank_next,
+                                     const double* gamma, double* out, pem_stream_t stream) {
+    if (m < 1 || m > 64 * MAX_NC) return pem::fail(PEM_ERR_INVALID_ARG, "pem_quantiles: 1 <= m <= %d columns", 64 * MAX_NC);
+    if (nq < 1 || nq > PEM_QUANTILE_MAX_Q) return pem::fail(PEM_ERR_INVALID_ARG, "pem_quantiles: 1 <= nq <= %d per call", PEM_QUANTILE_MAX_Q);
+    if (n == 0) return pem::fail(PEM_ERR_INVALID_ARG, "pem_quantiles: no samples");
+    if (ld < (size_t)m) return pem::fail(PEM_ERR_INVALID_ARG, "pem_quantiles: leading dimension smaller than m");
+    if (!data || !rank_prev || !rank_next || !gamma || !out) return pem::fail(PEM_ERR_INVALID_ARG, "pem_quantiles: NULL array");
+    for (int q = 0; q < nq; ++q)
+        if (rank_prev[q] >= n || rank_next[q] >= n || rank_prev[q] > rank_next[q])
+            return pem::fail(PEM_ERR_INVALID_ARG, "pem_quantiles: ranks must satisfy prev <= next < n");
+    if (int rc = pem::check_device()) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nt = 2 * nq;
+    const int bins1 = pow2_at_most(LDS_WORDS / m, 4096), bins2 = pow2_at_most(LDS_WORDS / (m * nt), 4096);
+
+    // workspace: columns | targets | hist1 | hist2 | total -- kept between calls (grow-only, one per process; calls are
+    // serialised on it, and each one ends with a stream synchronisation before the next may touch it)
+    const size_t b_col = sizeof(Column) * m, b_tg = sizeof(Target) * m * nt;
+    const size_t b_h1 = sizeof(unsigned) * (size_t)m * bins1, b_h2 = sizeof(unsigned) * (size_t)m * nt * bins2;
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_tg = up(b_col), o_h1 = o_tg + up(b_tg), o_h2 = o_h1 + up(b_h1), o_tot = o_h2 + up(b_h2);
+    static std::mutex mu;
+    static char* ws_buf = nullptr;
+    static size_t ws_cap = 0, cand_cap = 0;
+    static u64* cand_buf = nullptr;
+    static int ws_dev = -1;
+    std::lock_guard<std::mutex> lock(mu);
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != ws_dev || ws_cap < o_tot + 256) {
+        if (ws_buf) (void)hipFree(ws_buf);
+        if (cand_buf && dev != ws_dev) {
+            (void)hipFree(cand_buf);
+            cand_buf = nullptr;
+            cand_cap = 0;
+        }
+        ws_buf = nullptr;
+        ws_cap = 0;
+        HIP_TRY(hipMalloc(&ws_buf, o_tot + 256));
+        ws_cap = o_tot + 256;
+        ws_dev = dev;
+    }
+    char* ws = ws_buf;
+    Column* col = reinterpret_cast<Column*>(ws);
+    Target* tg = reinterpret_cast<Target*>(ws + o_tg);
+    unsigned* hist1 = reinterpret_cast<unsigned*>(ws + o_h1);
+    unsigned* hist2 = reinterpret_cast<unsigned*>(ws + o_h2);
+    u64* total = reinterpret_cast<u64*>(ws + o_tot);
+    auto cleanup = [&](int code) {
+        (void)hipStreamSynchronize(st);
+        return code;
+    };
+#define Q_TRY(expr)                                                                                          \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess) return cleanup(pem::fail(PEM_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_))); \
+    } while (0)
+
+    Wanted w{};
+    for (int q = 0; q < nq; ++q) {
+        w.prev[q] = rank_prev[q];
+        w.next[q] = rank_next[q];
+        w.gamma[q] = gamma[q];
+    }
+    Q_TRY(hipMemsetAsync(hist1, 0, o_tot + 256 - o_h1, st));            // hist1, hist2, total
+
+    const long long rpw = m <= 64 ? 64 / m : 1, groups = ((long long)n + rpw - 1) / rpw;
+    long long blocks = (groups + (long long)QWAVES * UNROLL - 1) / ((long long)QWAVES * UNROLL);
+    if (blocks > 256 * 2) blocks = 256 * 2;
+    const dim3 grid((unsigned)blocks), blk(QBLOCK);
+    const int cblocks = (m + 63) / 64;
+    const int nc = m <= 64 ? 1 : (m <= 128 ? 2 : 4);
+    const size_t lds1 = (size_t)m * bins1 * 4, lds2 = (size_t)m * nt * bins2 * 4;
+#define Q_LDS(KERN) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+#define Q_BY_NC(CALL)              \
+    do {                           \
+        if (nc == 1) { CALL(1); }  \
+        else if (nc == 2) { CALL(2); } \
+        else { CALL(4); }          \
+    } while (0)
+#define Q_BY_NT(CALL, NC_)             \
+    do {                               \
+        if (nt == 2) { CALL(NC_, 2); } \
+        else if (nt == 4) { CALL(NC_, 4); } \
+        else { CALL(NC_, 6); }         \
+    } while (0)
+    hipLaunchKernelGGL(init_columns_kernel, dim3(cblocks), dim3(64), 0, st, col, tg, m, nq, w);
+#define Q_MINMAX(NC_) hipLaunchKernelGGL(minmax_kernel<NC_>, grid, blk, 0, st, (long long)n, m, ld, data, col)
+    Q_BY_NC(Q_MINMAX);
+    hipLaunchKernelGGL(scale_columns_kernel, dim3(cblocks), dim3(64), 0, st, col, m, bins1);
+#define Q_HIST1(NC_)                                                                                       \
+    Q_LDS(hist1_kernel<NC_>);                                                                              \
+    hipLaunchKernelGGL(hist1_kernel<NC_>, grid, blk, lds1, st, (long long)n, m, ld, data, col, bins1, hist1)
+    Q_BY_NC(Q_HIST1);
+    hipLaunchKernelGGL(decide1_kernel, dim3((unsigned)(m * nt)), dim3(64), 0, st, m, nt, col, hist1, bins1, tg);
+#define Q_HIST2_(NC_, NT_)                                                                                                  \
+    Q_LDS((hist2_kernel<NC_, NT_>));                                                                                        \
+    hipLaunchKernelGGL((hist2_kernel<NC_, NT_>), grid, blk, lds2, st, (long long)n, m, ld, data, col, tg, bins1, bins2, hist2)
+#define Q_HIST2(NC_) Q_BY_NT(Q_HIST2_, NC_)
+    Q_BY_NC(Q_HIST2);
+    hipLaunchKernelGGL(decide2_kernel, dim3((unsigned)(m * nt)), dim3(64), 0, st, nt, hist2, bins2, tg);
+    hipLaunchKernelGGL(layout_kernel, dim3(1), dim3(64 * MAX_NC), 0, st, m, nt, tg, total);
+    Q_TRY(hipGetLastError());
+    u64 h_total = 0;
+    Q_TRY(hipMemcpyAsync(&h_total, total, sizeof(u64), hipMemcpyDeviceToHost, st));
+    Q_TRY(hipStreamSynchronize(st));
+    if (cand_cap < h_total + 1) {
+        if (cand_buf) (void)hipFree(cand_buf);
+        cand_buf = nullptr;
+        cand_cap = 0;
+        Q_TRY(hipMalloc(&cand_buf, (size_t)(h_total + 1) * sizeof(u64)));
+        cand_cap = h_total + 1;
+    }
+    u64* cand = cand_buf;
+#define Q_COMPACT_(NC_, NT_) \
+    hipLaunchKernelGGL((compact_kernel<NC_, NT_>), grid, blk, 0, st, (long long)n, m, ld, data, col, tg, bins1, bins2, cand)
+#define Q_COMPACT(NC_) Q_BY_NT(Q_COMPACT_, NC_)
+    Q_BY_NC(Q_COMPACT);
+    hipLaunchKernelGGL(select_kernel, dim3((unsigned)(m * nt)), blk, 0, st, nt, tg, cand);
+    hipLaunchKernelGGL(finish_kernel, dim3((unsigned)((m * nq + 63) / 64)), dim3(64), 0, st, m, nq, col, tg, w, out);
+    Q_TRY(hipGetLastError());
+#undef Q_COMPACT
+#undef Q_COMPACT_
+#undef Q_HIST2
+#undef Q_HIST2_
+#undef Q_HIST1
+#undef Q_MINMAX
+#undef Q_BY_NT
+#undef Q_BY_NC
+#undef Q_LDS
+#undef Q_TRY
+    return cleanup(PEM_OK);
+}

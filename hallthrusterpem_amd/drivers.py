@@ -22,6 +22,54 @@ from .distributed import shard_bounds
 COORDS_STR_ID = '_coords'      # amisc.typing.COORDS_STR_ID as the reference uses it (gen_data.py:143, plume.py:157)
 
 
+# ------------------------------------------------------------------------------------------- percentiles over the samples
+def column_percentiles(a, percentiles):
+    """`np.percentile(a, percentiles, axis=0)` (method 'linear') of a CUDA tensor `a` of shape (n, ...), bit for bit, by exact
+    selection on the device (`pem_quantiles_f64_dev`, csrc/pem_quantile.hip) -- the percentiles of gen_data.py:125-174 and
+    monte_carlo.py:363-658 at sizes where a sort-based quantile gives up (torch.quantile: 2^24 values per column).
+    Returns a CUDA tensor of shape (len(percentiles), ...) (or (...) for a scalar percentile); a column that holds a NaN
+    gives NaN, as numpy does."""
+    import ctypes as C
+    import torch
+    from . import _lib
+    scalar = np.ndim(percentiles) == 0
+    # numpy's own index arithmetic (numpy/lib/_function_base_impl.py: percentile -> _quantile, method 'linear')
+    q = np.true_divide(np.atleast_1d(np.asarray(percentiles, dtype=np.float64)), np.float64(100))
+    if not np.all((q >= 0) & (q <= 1)):
+        raise ValueError('Percentiles must be in the range [0, 100]')
+    n = int(a.shape[0])
+    if n == 0:
+        raise ValueError('no samples')
+    virtual = (n - 1) * q
+    prev = np.floor(virtual)
+    nxt = prev + 1
+    above = virtual >= n - 1
+    prev[above], nxt[above] = -1, -1                       # "take the max value of the array": index -1
+    gamma = virtual - prev                                  # (numpy takes the weight from the clipped index as well)
+    rank_prev = np.where(prev < 0, n - 1, prev).astype(np.uint64)
+    rank_next = np.where(nxt < 0, n - 1, nxt).astype(np.uint64)
+    flat = a.double().reshape(n, -1)
+    if not flat.is_contiguous():
+        flat = flat.contiguous()
+    m = flat.shape[1]
+    order = np.arange(q.size)                               # three quantiles per launch
+    out = torch.empty((q.size, m), dtype=torch.float64, device=flat.device)
+    lib = _lib.load()
+    stream = C.c_void_p(torch.cuda.current_stream(flat.device).cuda_stream)
+    with torch.cuda.device(flat.device):
+        for c0 in range(0, m, 256):
+            mc = min(256, m - c0)
+            for i0 in range(0, q.size, 3):
+                idx = order[i0:i0 + 3]
+                rp, rn, gm = (np.ascontiguousarray(v[idx]) for v in (rank_prev, rank_next, gamma))
+                part = torch.empty((idx.size, mc), dtype=torch.float64, device=flat.device)
+                _lib.check(lib.pem_quantiles_f64_dev(n, mc, C.c_void_p(flat.data_ptr() + 8 * c0), m, idx.size, C.c_void_p(rp.ctypes.data),
+                                                     C.c_void_p(rn.ctypes.data), C.c_void_p(gm.ctypes.data), C.c_void_p(part.data_ptr()), stream))
+                out[torch.from_numpy(idx).to(flat.device), c0:c0 + mc] = part
+    out = out.reshape((q.size,) + tuple(a.shape[1:]))
+    return out[0] if scalar else out
+
+
 # ------------------------------------------------------------------------------------------- NaN / outlier masks
 def filter_outputs(outputs: dict, iqr_factor: float = 1.5):
     """NaN and interquartile-range outlier masks per output variable; mirrors gen_data.py:125-174.
@@ -42,7 +90,7 @@ def filter_outputs(outputs: dict, iqr_factor: float = 1.5):
             rest = tuple(range(1, a.dim()))
             per_sample = int(np.prod(a.shape[1:])) if a.dim() > 1 else 1
             nan_idx[var] = torch.isnan(a).any(dim=rest) if rest else torch.isnan(a)
-            q = torch.quantile(a, torch.tensor([0.25, 0.75], dtype=a.dtype, device=a.device), dim=0)
+            q = column_percentiles(a, [25.0, 75.0]) if a.is_cuda else torch.quantile(a, torch.tensor([0.25, 0.75], dtype=a.dtype), dim=0)
             iqr = q[1] - q[0]
             outside = (a < q[0] - iqr_factor * iqr) | (a > q[1] + iqr_factor * iqr)
             count = outside.sum(dim=rest) if rest else outside.long()

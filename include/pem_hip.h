@@ -256,6 +256,18 @@ int pem_sparse_grid_values_f64_dev(size_t n, int n_dim, int n_beta, const int32_
                                    const double* values, int n_out, const double* t, size_t ld, double* out,
                                    size_t ld_out, pem_stream_t stream);
 
+/* ---- per-column order statistics over the sample axis -------------------------------------------------------------
+ * The percentiles of scripts/gen_data.py:125-174 (`np.percentile(arr, 25 | 75, axis=0)`, NaN / interquartile-range masks) and
+ * of scripts/pem_v0/monte_carlo.py:363-658 (5 / 50 / 95 % bands) at forward-UQ sizes, by exact radix selection instead of a
+ * sort (csrc/pem_quantile.hip).  data: [n][ld] row-major device array of which columns 0..m-1 are used, m <= 256 (ld = m:
+ * fully coalesced); for quantile i the caller gives the two ranks
+ * numpy's method 'linear' reads (rank_prev[i] <= rank_next[i] < n) and its weight gamma[i] (HOST arrays);
+ * out[i][c] = _lerp(x_(rank_prev[i]), x_(rank_next[i]), gamma[i]) of column c, NaN if the column holds a NaN -- equal to
+ * np.percentile bit for bit.  nq <= PEM_QUANTILE_MAX_Q per call.  Allocates its workspace and synchronises the stream.   */
+#define PEM_QUANTILE_MAX_Q 3
+int pem_quantiles_f64_dev(size_t n, int m, const double* data, size_t ld, int nq, const uint64_t* rank_prev, const uint64_t* rank_next,
+                          const double* gamma, double* out, pem_stream_t stream);
+
 /* ---- fused Monte-Carlo evaluation -----------------------------------------------------------------
  * sample_inputs + predict of scripts/gen_data.py:238-239 in ONE launch: the 15 coupled inputs of global samples
  * first_index .. first_index+n-1 are generated in registers from the counter-based design (kind/a/b as for

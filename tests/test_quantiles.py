@@ -1,0 +1,72 @@
+"""pem_quantiles_f64_dev / drivers.column_percentiles (csrc/pem_quantile.hip): exact per-column percentiles over the sample axis
+-- the p25 / p75 of the IQR masks (gen_data.py:125-174) and the 5 / 50 / 95 % bands of monte_carlo.py:363-658 -- held to
+np.percentile BIT FOR BIT (order statistics are selected, not estimated, and the interpolation is numpy's own _lerp)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(a, pcts):
+    import torch
+    from hallthrusterpem_amd.drivers import column_percentiles
+    want = np.percentile(a, pcts, axis=0)
+    got = column_percentiles(torch.from_numpy(np.ascontiguousarray(a)).cuda(), pcts).cpu().numpy()
+    assert got.shape == want.shape
+    assert np.array_equal(got, want, equal_nan=True), (np.abs(got - want).max(), a.shape, pcts)
+
+
+@pytest.mark.parametrize('shape', [(1, 1), (2, 3), (3, 91), (777, 91), (100_003, 91), (50_000, 1), (4_000, 64), (4_000, 65), (3_000, 129),
+                                   (2_000, 256), (1_500, 300), (20_000, 7, 13)])
+def test_random_columns_equal_numpy(shape):
+    rng = np.random.default_rng(sum(shape))
+    a = rng.lognormal(0.0, 3.0, shape) * np.where(rng.random(shape) < 0.3, -1.0, 1.0)      # 30 decades, both signs
+    _check(a, [25.0, 75.0])
+    _check(a, [5.0, 50.0, 95.0])
+    _check(a, 50.0)
+    _check(a, [100.0, 0.0, 33.3, 99.999, 1e-3])             # unsorted, the ends, more than three per call
+
+
+def test_ties_constants_and_special_values():
+    rng = np.random.default_rng(5)
+    n = 300_000
+    a = rng.lognormal(0.0, 1.0, (n, 6))
+    a[:, 0] = 7.25                                           # a constant column
+    a[rng.random(n) < 0.4, 1] = 1e-20                       # 40 % ties at the minimum (the profile of invalid samples): lists longer than LDS
+    a[:, 2] = rng.integers(0, 5, n)                         # five distinct values
+    a[::7, 3] = np.inf
+    a[1::7, 3] = -np.inf
+    a[:, 4] = np.where(rng.random(n) < 0.5, 0.0, -0.0)      # signed zeros only
+    a[12345, 5] = np.nan                                     # one NaN: the column's percentiles are NaN
+    for pcts in ([25.0, 75.0], [5.0, 50.0, 95.0], [0.0, 10.0, 40.0, 100.0]):
+        _check(a, pcts)
+    b = np.full((1000, 3), np.nan)                           # nothing but NaN
+    b[:, 1] = 1.0
+    _check(b, [25.0, 75.0])
+    d = rng.standard_normal((4097, 2))                       # denormals and huge values in one column
+    d[:, 0] *= 1e-310
+    d[::2, 1] *= 1e300
+    _check(d, [25.0, 50.0, 75.0])
+
+
+def test_filter_outputs_on_the_device_equals_the_host_path_at_a_size_torch_quantile_refuses():
+    """drivers.filter_outputs (gen_data.py:125-174) on CUDA tensors goes through the selection kernel: identical masks to the
+    numpy branch, also where one column is longer than torch.quantile's 2^24 limit."""
+    import torch
+    from hallthrusterpem_amd.drivers import filter_outputs
+    rng = np.random.default_rng(11)
+    n = 200_000
+    out = {'T_c': rng.normal(0.08, 0.01, n), 'j_ion': rng.lognormal(0.0, 1.0, (n, 91)), 'j_ion_coords': np.zeros((n, 91))}
+    out['T_c'][::1000] = 5.0                                 # outliers
+    out['j_ion'][5::5000] *= 1e4
+    out['j_ion'][7, 3] = np.nan
+    nan_h, outl_h = filter_outputs(out)
+    dev = {k: torch.from_numpy(v).cuda() for k, v in out.items()}
+    nan_d, outl_d = filter_outputs(dev)
+    for k in nan_h:
+        assert np.array_equal(nan_h[k], nan_d[k].cpu().numpy()) and np.array_equal(outl_h[k], outl_d[k].cpu().numpy())
+    assert outl_h['T_c'].sum() >= n // 1000 and nan_h['j_ion'].sum() == 1
+    big = rng.standard_normal(17_000_000)                    # > 2^24 samples of a scalar QoI
+    from hallthrusterpem_amd.drivers import column_percentiles
+    got = column_percentiles(torch.from_numpy(big).cuda(), [25.0, 75.0]).cpu().numpy()
+    assert np.array_equal(got, np.percentile(big, [25.0, 75.0]))
