@@ -145,6 +145,13 @@ def forward_uq(n: int, seed: int = 0, method: str = 'mc', profile: bool = False,
     return out
 
 
+def percentile_bands(outputs: dict, percentiles=(5.0, 50.0, 95.0), names=('V_cc', 'div_angle', 'T_c', 'j_ion')):
+    """The 5 / 50 / 95 % bands monte_carlo.py:363-658 draws from its prior / posterior predictive samples
+    (`np.percentile(ys, x, axis=0)`), for the device-resident outputs of `forward_uq`: {name: (len(percentiles), ...) CUDA
+    tensor}, equal to numpy's values bit for bit (`column_percentiles`).  Samples flagged `invalid` are kept, as there."""
+    return {k: column_percentiles(outputs[k], list(percentiles)) for k in names if k in outputs}
+
+
 def generate_data(system, description: str, num_samples: int = 500, executor=None, verbose: bool = False,
                   iqr_factor: float = 1.5, device_resident: bool = False):
     """gen_data.py:218-258, same signature, on a `system.PemV0System`: sample the input space (calibration and

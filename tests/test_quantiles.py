@@ -70,3 +70,13 @@ def test_filter_outputs_on_the_device_equals_the_host_path_at_a_size_torch_quant
     from hallthrusterpem_amd.drivers import column_percentiles
     got = column_percentiles(torch.from_numpy(big).cuda(), [25.0, 75.0]).cpu().numpy()
     assert np.array_equal(got, np.percentile(big, [25.0, 75.0]))
+
+
+def test_percentile_bands_of_a_forward_uq_campaign():
+    from hallthrusterpem_amd import drivers
+    out = drivers.forward_uq(300_000, seed=4, keep_profile=True)
+    bands = drivers.percentile_bands(out)
+    assert set(bands) == {'V_cc', 'div_angle', 'T_c', 'j_ion'} and bands['j_ion'].shape == (3, 91) and bands['T_c'].shape == (3,)
+    for k, v in bands.items():
+        assert np.array_equal(v.cpu().numpy(), np.percentile(out[k].cpu().numpy(), [5.0, 50.0, 95.0], axis=0), equal_nan=True)
+    assert bool((bands['j_ion'][0] <= bands['j_ion'][1]).all() and (bands['j_ion'][1] <= bands['j_ion'][2]).all())
