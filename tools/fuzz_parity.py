@@ -82,7 +82,8 @@ def prior_campaign(batches, oc, constants, pem_v0_coupled, div_err, rel_err, n=1
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--seeds', type=int, default=40, help='seeds 0 .. SEEDS-1')
+    ap.add_argument('--seeds', type=int, default=40, help='seeds FIRST .. SEEDS-1')
+    ap.add_argument('--first-seed', type=int, default=0, help='first seed of the range (campaigns longer than one GPU call are run in pieces)')
     ap.add_argument('--seed-list', type=int, nargs='*', default=[], help='further seeds (e.g. the ones earlier campaigns failed on)')
     ap.add_argument('--n', type=int, default=20_000)
     ap.add_argument('--dump', default='', help='write the worst sample of every quantity (inputs, got, want) to this .npz')
@@ -141,7 +142,7 @@ def main():
         note(f'{tag}.div_angle', d['err_div'], **d)
         note(f'{tag}.T_c', d['err_tc'], **d)
 
-    seeds = list(range(args.seeds)) + [s_ for s_ in args.seed_list if s_ >= args.seeds]
+    seeds = list(range(args.first_seed, args.seeds)) + [s_ for s_ in args.seed_list if not args.first_seed <= s_ < args.seeds]
     for it, seed in enumerate(seeds):
         seed_now[0] = seed
         if it % 25 == 0:
@@ -205,7 +206,7 @@ def main():
                 bR = pr.plume_bounds(tR, p['I_B0'])
             g = current_density(p, sweep_radius=radii[0] if len(radii) == 1 else np.array(radii))
             plume_check(f'plume[R={len(radii)}]', g, w, bR, seed, inputs=p)
-    print(f'{len(seeds)} seeds x {args.n} wild samples (seeds 0..{args.seeds - 1}' + (f' + {args.seed_list}' if args.seed_list else '') + '):')
+    print(f'{len(seeds)} seeds x {args.n} wild samples (seeds {args.first_seed}..{args.seeds - 1}' + (f' + {args.seed_list}' if args.seed_list else '') + '):')
     print('NaN / inf / invalid patterns identical everywhere; worst errors (1e-10 = at the bound) and the cancellation they met:')
     for key, v in sorted(worst.items()):
         e = extra[key]
