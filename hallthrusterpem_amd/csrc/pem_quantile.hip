@@ -17,8 +17,8 @@
 //   4. those values are copied out (exact sizes are known from pass 3; ranks that share a sub-bin share a list).
 // Then one workgroup per list sorts it in LDS and reads the ranks off; a list too long for LDS -- heavy ties, e.g. the
 // 1e-20 profile of invalid samples -- is narrowed by further histograms over the list itself until it fits or is one value.
-// Monotone binning is all the method needs: bin(k) = floor((k - lo) * BINS / (hi - lo + 1)) in double arithmetic never
-// decreases with the key, so everything in a lower bin is <= everything in a higher one and equal keys share a bin.
+// Monotone binning is all the method needs: a bin index that never decreases with the key, so that everything in a lower
+// bin is <= everything in a higher one and equal keys share a bin.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -47,21 +47,33 @@ __device__ __forceinline__ double value_of(u64 k) {
     const u64 b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
     return __longlong_as_double((long long)b);
 }
-__device__ __forceinline__ int bin_of(u64 k, u64 lo, double inv, int bins) {
+// Binning of the streaming passes, in integer arithmetic (a u64 -> f64 conversion is six instructions on this chip, and the
+// passes over 7 GB were bound by them): d = (k - lo) >> shift fits 31 bits, bin = floor(d * mult / 2^32) with
+// mult = floor(2^32 BINS / (D + 1)), D = (hi - lo) >> shift -- never decreases with the key and stays below BINS; the low
+// 32 bits of the product are the position inside the bin, scaled to BINS2 sub-bins the same way.
+struct Scale {
+    u64 lo;
+    unsigned mult;
+    int shift;
+};
+__device__ __forceinline__ int bin_of(u64 k, const Scale& s, unsigned& frac) {
+    const unsigned d = (unsigned)((k - s.lo) >> s.shift);
+    const u64 p = (u64)d * s.mult;
+    frac = (unsigned)p;
+    return (int)(p >> 32);
+}
+__device__ __forceinline__ int subbin_of(unsigned frac, int bins2) { return (int)__umulhi(frac, (unsigned)bins2); }
+// the select kernel's own refinement (rare, over short lists): bins in double arithmetic over any key range
+__device__ __forceinline__ int bin_of_d(u64 k, u64 lo, double inv, int bins) {
     const int b = (int)((double)(k - lo) * inv);
     return b < bins - 1 ? b : bins - 1;
-}
-// the sub-bin inside bin b of the same map (fractional part of the scaled offset)
-__device__ __forceinline__ int subbin_of(u64 k, u64 lo, double inv, int b, int bins2) {
-    const double f = (double)(k - lo) * inv - (double)b;
-    const int s = (int)(f * (double)bins2);
-    return s < 0 ? 0 : (s < bins2 - 1 ? s : bins2 - 1);
 }
 
 struct Column {          // per column
     u64 kmin, kmax;
     int has_nan, pad;
-    double inv1;         // BINS1 / (kmax - kmin + 1)
+    unsigned mult;       // floor(2^32 BINS1 / (((kmax - kmin) >> shift) + 1))
+    int shift;           // so that (kmax - kmin) >> shift < 2^31
 };
 struct Target {          // per (column, wanted rank)
     u64 rank;            // in: 0-based rank in the column; then the rank inside the current bin / list
@@ -198,7 +210,12 @@ __global__ void scale_columns_kernel(Column* col, int m, int bins1) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < m) {
         const Column k = col[c];
-        col[c].inv1 = k.kmax >= k.kmin ? (double)bins1 / ((double)(k.kmax - k.kmin) + 1.0) : 0.0;
+        const u64 span = k.kmax >= k.kmin ? k.kmax - k.kmin : 0;
+        int shift = 0;
+        while ((span >> shift) >> 31) ++shift;
+        col[c].shift = shift;
+        const u64 mult = (((u64)bins1) << 32) / ((span >> shift) + 1);        // >= 2^32 when there are fewer keys than bins:
+        col[c].mult = mult > 0xffffffffull ? 0xffffffffu : (unsigned)mult;      // capped (two keys may then share a bin: still monotone)
     }
 }
 
@@ -210,17 +227,20 @@ __global__ __launch_bounds__(QBLOCK) void hist1_kernel(long long n, int m, size_
     for (int i = threadIdx.x; i < m * bins1; i += QBLOCK) lds_hist[i] = 0;
     __syncthreads();
     const Lanes L(m, threadIdx.x & 63);
-    u64 klo[NC];
-    double inv[NC];
+    Scale sc[NC];
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
         const int c = L.col0 + 64 * j;
         const bool on = L.active && c < m;
-        klo[j] = on ? col[c].kmin : 0;
-        inv[j] = on ? col[c].inv1 : 0.0;
+        sc[j].lo = on ? col[c].kmin : 0;
+        sc[j].mult = on ? col[c].mult : 0;
+        sc[j].shift = on ? col[c].shift : 0;
     }
     stream_values<NC>(n, m, ld, data, L, [&](int j, int c, double x) {
-        if (x == x) atomicAdd(&lds_hist[c * bins1 + bin_of(key_of(x), klo[j], inv[j], bins1)], 1u);
+        if (x == x) {
+            unsigned frac;
+            atomicAdd(&lds_hist[c * bins1 + bin_of(key_of(x), sc[j], frac)], 1u);
+        }
     });
     __syncthreads();
     for (int i = threadIdx.x; i < m * bins1; i += QBLOCK) {
@@ -297,15 +317,15 @@ __global__ __launch_bounds__(QBLOCK) void hist2_kernel(long long n, int m, size_
     for (int i = threadIdx.x; i < m * NT * bins2; i += QBLOCK) lds_hist[i] = 0;
     __syncthreads();
     const Lanes L(m, threadIdx.x & 63);
-    u64 klo[NC];
-    double inv[NC];
+    Scale sc[NC];
     int tb[NC][NT];
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
         const int c = L.col0 + 64 * j;
         const bool on = L.active && c < m;
-        klo[j] = on ? col[c].kmin : 0;
-        inv[j] = on ? col[c].inv1 : 0.0;
+        sc[j].lo = on ? col[c].kmin : 0;
+        sc[j].mult = on ? col[c].mult : 0;
+        sc[j].shift = on ? col[c].shift : 0;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             // targets of a column often share a bin: each DISTINCT bin is counted once, under the first target that has it
@@ -319,10 +339,11 @@ __global__ __launch_bounds__(QBLOCK) void hist2_kernel(long long n, int m, size_
     stream_values<NC>(n, m, ld, data, L, [&](int j, int c, double x) {
         if (x == x) {
             const u64 k = key_of(x);
-            const int b = bin_of(k, klo[j], inv[j], bins1);
+            unsigned frac;
+            const int b = bin_of(k, sc[j], frac);
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-                if (tb[j][t] == b) atomicAdd(&lds_hist[(c * NT + t) * bins2 + subbin_of(k, klo[j], inv[j], b, bins2)], 1u);
+                if (tb[j][t] == b) atomicAdd(&lds_hist[(c * NT + t) * bins2 + subbin_of(frac, bins2)], 1u);
         }
     });
     __syncthreads();
@@ -398,15 +419,15 @@ template <int NC, int NT>
 __global__ __launch_bounds__(QBLOCK) void compact_kernel(long long n, int m, size_t ld, const double* __restrict__ data, const Column* __restrict__ col,
                                                           Target* __restrict__ tg, int bins1, int bins2, u64* __restrict__ cand) {
     const Lanes L(m, threadIdx.x & 63);
-    u64 klo[NC];
-    double inv[NC];
+    Scale sc[NC];
     int tb1[NC][NT], tb2[NC][NT];
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
         const int c = L.col0 + 64 * j;
         const bool on = L.active && c < m;
-        klo[j] = on ? col[c].kmin : 0;
-        inv[j] = on ? col[c].inv1 : 0.0;
+        sc[j].lo = on ? col[c].kmin : 0;
+        sc[j].mult = on ? col[c].mult : 0;
+        sc[j].shift = on ? col[c].shift : 0;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const bool own = on && !tg[c * NT + t].done && tg[c * NT + t].owner == t;       // only list owners collect
@@ -417,10 +438,11 @@ __global__ __launch_bounds__(QBLOCK) void compact_kernel(long long n, int m, siz
     stream_values<NC>(n, m, ld, data, L, [&](int j, int c, double x) {
         if (x == x) {
             const u64 k = key_of(x);
-            const int b = bin_of(k, klo[j], inv[j], bins1);
+            unsigned frac;
+            const int b = bin_of(k, sc[j], frac);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                if (tb1[j][t] == b && subbin_of(k, klo[j], inv[j], b, bins2) == tb2[j][t]) {
+                if (tb1[j][t] == b && subbin_of(frac, bins2) == tb2[j][t]) {
                     Target& T = tg[c * NT + t];
                     cand[T.offset + atomicAdd(&T.cursor, 1ull)] = k;
                 }
@@ -517,7 +539,7 @@ __global__ __launch_bounds__(QBLOCK) void select_kernel(int nt, Target* __restri
         const double inv = 1024.0 / ((double)(hi - lo) + 1.0);
         for (u64 i = threadIdx.x; i < len; i += QBLOCK) {
             const u64 k = list[i];
-            if (k >= lo && k <= hi) atomicAdd(&hist[bin_of(k, lo, inv, 1024)], 1u);
+            if (k >= lo && k <= hi) atomicAdd(&hist[bin_of_d(k, lo, inv, 1024)], 1u);
         }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -543,7 +565,7 @@ __global__ __launch_bounds__(QBLOCK) void select_kernel(int nt, Target* __restri
         mx = 0;
         for (u64 i = threadIdx.x; i < len; i += QBLOCK) {
             const u64 k = list[i];
-            if (k >= lo && k <= hi && bin_of(k, lo, inv, 1024) == keep) {
+            if (k >= lo && k <= hi && bin_of_d(k, lo, inv, 1024) == keep) {
                 mn = k < mn ? k : mn;
                 mx = k > mx ? k : mx;
             }
