@@ -50,6 +50,8 @@ SIGNATURES = {
     'pem_coupled_mc_f64_dev': (C.c_int, [_sz, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, _dp, _dp, _dp, _f8, _f8, _dp, _sz] + [_dp] * 7 + [_dp]),
     'pem_sparse_predict_f64_dev': (C.c_int, [_sz, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _sz, _dp, _sz, _dp]),
     'pem_sparse_grid_values_f64_dev': (C.c_int, [_sz, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _sz, _dp, _sz, _dp]),
+    'pem_key_minmax_f64_dev': (C.c_int, [_sz, C.c_int, _dp, _sz, _dp, _dp, _dp, _dp]),
+    'pem_range_hist_f64_dev': (C.c_int, [_sz, C.c_int, _dp, _sz, C.c_int, _dp, _dp, C.c_int, _dp, _dp]),
     'pem_quantiles_f64_dev': (C.c_int, [_sz, C.c_int, _dp, _sz, C.c_int, _dp, _dp, _dp, _dp, _dp]),
     'pem_sobol_partial_f64_dev': (C.c_int, [_sz, C.c_int, _sz, _dp, _dp, _dp, _dp, C.c_int, _dp]),
     'pem_coupled_f32_dev': (C.c_int, [_sz, C.c_float, C.c_float, _dp, _sz, _dp, _sz, _dp, _dp]),

@@ -596,6 +596,79 @@ __global__ void finish_kernel(int m, int nq, const Column* __restrict__ col, con
     out[(size_t)q * m + c] = r;
 }
 
+// ---- the multi-rank form: histograms over caller-given key ranges -----------------------------------------------------------
+// Samples sharded over ranks cannot be copied out and sorted in one place cheaply, but histograms add: every rank counts its
+// own values inside the current range of every wanted rank, the counts are all-reduced (<= 144 KB), all ranks pick the same
+// bin and narrow the range to it -- until a range is one key (hallthrusterpem_amd/percentiles.py drives the levels).
+// Range r of column c: keys klo[c][r] .. khi[c][r]; d = (k - klo) >> shift with shift such that the span fits 31 bits;
+// bin = d when the shifted span is smaller than `bins` (every key its own bin: the next range is a single key), else
+// floor(d mult / 2^32), mult = min(2^32 - 1, floor(2^32 bins / (span' + 1))).  percentiles.py inverts exactly this map.
+struct RangeScale {
+    u64 lo, hi;
+    unsigned mult;
+    int shift, identity;
+};
+__device__ __forceinline__ RangeScale range_scale(u64 lo, u64 hi, int bins) {
+    RangeScale r;
+    r.lo = lo;
+    r.hi = hi;
+    const u64 span = hi >= lo ? hi - lo : 0;
+    int shift = 0;
+    while ((span >> shift) >> 31) ++shift;
+    const u64 d = span >> shift;
+    r.shift = shift;
+    r.identity = d < (u64)bins;
+    const u64 mult = (((u64)bins) << 32) / (d + 1);
+    r.mult = mult > 0xffffffffull ? 0xffffffffu : (unsigned)mult;
+    return r;
+}
+
+template <int NC, int NR>
+__global__ __launch_bounds__(QBLOCK) void range_hist_kernel(long long n, int m, size_t ld, const double* __restrict__ data,
+                                                             const u64* __restrict__ klo, const u64* __restrict__ khi, int bins,
+                                                             unsigned* __restrict__ hist) {
+    extern __shared__ unsigned lds_hist[];
+    for (int i = threadIdx.x; i < m * NR * bins; i += QBLOCK) lds_hist[i] = 0;
+    __syncthreads();
+    const Lanes L(m, threadIdx.x & 63);
+    RangeScale rs[NC][NR];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const int c = L.col0 + 64 * j;
+        const bool on = L.active && c < m;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) rs[j][r] = on ? range_scale(klo[c * NR + r], khi[c * NR + r], bins) : range_scale(1, 0, bins);
+    }
+    stream_values<NC>(n, m, ld, data, L, [&](int j, int c, double x) {
+        if (x == x) {
+            const u64 k = key_of(x);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const RangeScale& q = rs[j][r];
+                if (k >= q.lo && k <= q.hi) {
+                    const unsigned d = (unsigned)((k - q.lo) >> q.shift);
+                    const int b = q.identity ? (int)d : (int)(((u64)d * q.mult) >> 32);
+                    atomicAdd(&lds_hist[(c * NR + r) * bins + b], 1u);
+                }
+            }
+        }
+    });
+    __syncthreads();
+    for (int i = threadIdx.x; i < m * NR * bins; i += QBLOCK) {
+        const unsigned v = lds_hist[i];
+        if (v) atomicAdd(&hist[i], v);
+    }
+}
+
+__global__ void export_minmax_kernel(const Column* __restrict__ col, int m, u64* kmin, u64* kmax, int* has_nan) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < m) {
+        kmin[c] = col[c].kmin;
+        kmax[c] = col[c].kmax;
+        has_nan[c] = col[c].has_nan;
+    }
+}
+
 int pow2_at_most(long long x, int cap) {
     int p = 1;
     while (2LL * p <= x && 2 * p <= cap) p <<= 1;
@@ -736,4 +809,82 @@ extern "C" int pem_quantiles_f64_dev(size_t n, int m, const double* data, size_t
 #undef Q_LDS
 #undef Q_TRY
     return cleanup(PEM_OK);
+}
+
+
+// ---- multi-rank building blocks (one level each; hallthrusterpem_amd/percentiles.py) ---------------------------------------
+namespace {
+
+dim3 stream_grid(size_t n, int m) {
+    const long long rpw = m <= 64 ? 64 / m : 1, groups = ((long long)n + rpw - 1) / rpw;
+    long long blocks = (groups + (long long)QWAVES * UNROLL - 1) / ((long long)QWAVES * UNROLL);
+    if (blocks > 256 * 2) blocks = 256 * 2;
+    if (blocks < 1) blocks = 1;
+    return dim3((unsigned)blocks);
+}
+
+}  // namespace
+
+extern "C" int pem_key_minmax_f64_dev(size_t n, int m, const double* data, size_t ld, uint64_t* kmin, uint64_t* kmax, int32_t* has_nan,
+                                      pem_stream_t stream) {
+    if (m < 1 || m > 64 * MAX_NC) return pem::fail(PEM_ERR_INVALID_ARG, "pem_key_minmax: 1 <= m <= %d columns", 64 * MAX_NC);
+    if (ld < (size_t)m) return pem::fail(PEM_ERR_INVALID_ARG, "pem_key_minmax: leading dimension smaller than m");
+    if (!kmin || !kmax || !has_nan || (n && !data)) return pem::fail(PEM_ERR_INVALID_ARG, "pem_key_minmax: NULL array");
+    if (int rc = pem::check_device()) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Column* col = nullptr;
+    HIP_TRY(hipMalloc(&col, sizeof(Column) * m));
+    Target* no_targets = nullptr;
+    hipLaunchKernelGGL(init_columns_kernel, dim3((m + 63) / 64), dim3(64), 0, st, col, no_targets, m, 0, Wanted{});
+    if (n) {
+        const int nc = m <= 64 ? 1 : (m <= 128 ? 2 : 4);
+        const dim3 grid = stream_grid(n, m), blk(QBLOCK);
+        if (nc == 1) hipLaunchKernelGGL(minmax_kernel<1>, grid, blk, 0, st, (long long)n, m, ld, data, col);
+        else if (nc == 2) hipLaunchKernelGGL(minmax_kernel<2>, grid, blk, 0, st, (long long)n, m, ld, data, col);
+        else hipLaunchKernelGGL(minmax_kernel<4>, grid, blk, 0, st, (long long)n, m, ld, data, col);
+    }
+    hipLaunchKernelGGL(export_minmax_kernel, dim3((m + 63) / 64), dim3(64), 0, st, col, m, (u64*)kmin, (u64*)kmax, (int*)has_nan);
+    const hipError_t e = hipGetLastError();
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(col);
+    if (e != hipSuccess) return pem::fail(PEM_ERR_HIP, "pem_key_minmax: %s", hipGetErrorString(e));
+    return PEM_OK;
+}
+
+extern "C" int pem_range_hist_f64_dev(size_t n, int m, const double* data, size_t ld, int nr, const uint64_t* klo, const uint64_t* khi,
+                                      int bins, uint32_t* hist, pem_stream_t stream) {
+    if (m < 1 || m > 64 * MAX_NC) return pem::fail(PEM_ERR_INVALID_ARG, "pem_range_hist: 1 <= m <= %d columns", 64 * MAX_NC);
+    if (nr != 1 && nr != 2 && nr != 4 && nr != 6) return pem::fail(PEM_ERR_INVALID_ARG, "pem_range_hist: 1, 2, 4 or 6 ranges per column");
+    if (bins < 1 || (long long)m * nr * bins > LDS_WORDS)
+        return pem::fail(PEM_ERR_INVALID_ARG, "pem_range_hist: m * nr * bins must not exceed %d", LDS_WORDS);
+    if (ld < (size_t)m) return pem::fail(PEM_ERR_INVALID_ARG, "pem_range_hist: leading dimension smaller than m");
+    if (!klo || !khi || !hist || (n && !data)) return pem::fail(PEM_ERR_INVALID_ARG, "pem_range_hist: NULL array");
+    if (int rc = pem::check_device()) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemsetAsync(hist, 0, sizeof(uint32_t) * (size_t)m * nr * bins, st));
+    if (n == 0) return PEM_OK;
+    const int nc = m <= 64 ? 1 : (m <= 128 ? 2 : 4);
+    const dim3 grid = stream_grid(n, m), blk(QBLOCK);
+    const size_t lds = (size_t)m * nr * bins * 4;
+#define R_LAUNCH(NC_, NR_)                                                                                                       \
+    do {                                                                                                                         \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(range_hist_kernel<NC_, NR_>),                                   \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                      \
+        hipLaunchKernelGGL((range_hist_kernel<NC_, NR_>), grid, blk, lds, st, (long long)n, m, ld, data, (const u64*)klo,       \
+                           (const u64*)khi, bins, (unsigned*)hist);                                                              \
+    } while (0)
+#define R_BY_NR(NC_)                       \
+    do {                                   \
+        if (nr == 1) R_LAUNCH(NC_, 1);     \
+        else if (nr == 2) R_LAUNCH(NC_, 2); \
+        else if (nr == 4) R_LAUNCH(NC_, 4); \
+        else R_LAUNCH(NC_, 6);             \
+    } while (0)
+    if (nc == 1) R_BY_NR(1);
+    else if (nc == 2) R_BY_NR(2);
+    else R_BY_NR(4);
+#undef R_BY_NR
+#undef R_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return PEM_OK;
 }

@@ -268,6 +268,18 @@ int pem_sparse_grid_values_f64_dev(size_t n, int n_dim, int n_beta, const int32_
 int pem_quantiles_f64_dev(size_t n, int m, const double* data, size_t ld, int nq, const uint64_t* rank_prev, const uint64_t* rank_next,
                           const double* gamma, double* out, pem_stream_t stream);
 
+/* The multi-rank building blocks of the same selection (samples sharded over GPUs; hallthrusterpem_amd/percentiles.py drives the
+ * levels and all-reduces between them): per-column min / max of the order-preserving 64-bit image of the values (sign bit
+ * flipped, negative values inverted; kmin > kmax: no finite-or-infinite value) and a NaN flag; and the histogram of the keys
+ * inside caller-given ranges, nr = 1, 2, 4 or 6 ranges per column, hist[c][r][bin] (zeroed here), m * nr * bins <= 36864.
+ * Bin of key k in [klo, khi]: d = (k - klo) >> shift, shift the smallest with (khi - klo) >> shift < 2^31; bin = d if
+ * ((khi - klo) >> shift) < bins, else floor(d * mult / 2^32), mult = min(2^32 - 1, floor(2^32 * bins / (((khi - klo) >> shift) + 1))).
+ * All arrays on the device.  pem_key_minmax synchronises the stream; pem_range_hist does not.                                  */
+int pem_key_minmax_f64_dev(size_t n, int m, const double* data, size_t ld, uint64_t* kmin, uint64_t* kmax, int32_t* has_nan,
+                           pem_stream_t stream);
+int pem_range_hist_f64_dev(size_t n, int m, const double* data, size_t ld, int nr, const uint64_t* klo, const uint64_t* khi,
+                           int bins, uint32_t* hist, pem_stream_t stream);
+
 /* ---- fused Monte-Carlo evaluation -----------------------------------------------------------------
  * sample_inputs + predict of scripts/gen_data.py:238-239 in ONE launch: the 15 coupled inputs of global samples
  * first_index .. first_index+n-1 are generated in registers from the counter-based design (kind/a/b as for

@@ -129,3 +129,36 @@ def test_chunked_gather_without_a_process_group_is_the_local_result():
     pipe.step(evaluate)
     got = pipe.assemble()
     assert torch.equal(got[0], torch.arange(300, dtype=torch.float64)) and torch.equal(got[1], -got[0])
+
+
+def _percentile_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from hallthrusterpem_amd import percentiles as P
+        rng = np.random.default_rng(123)                         # every rank builds the same global array, keeps its rows
+        n, m = 30_011, 7
+        a = rng.lognormal(0.0, 3.0, (n, m)) * rng.choice([-1.0, 1.0], (n, m))
+        a[rng.random(n) < 0.3, 1] = 1e-20                        # 30 % ties at one value
+        a[:, 2] = 4.5                                            # a constant column
+        a[::11, 3] = np.inf
+        a[17, 4] = np.nan                                        # NaN on ONE rank only: the column is NaN everywhere
+        edges = [0, 17_000, n] if world == 2 else [0, 0, 12_345, n]          # ragged shards; world 3: rank 0 holds NO rows
+        mine = a[edges[rank]:edges[rank + 1]]
+        for pcts in ([25.0, 75.0], [5.0, 50.0, 95.0], 50.0, [0.0, 100.0, 33.3, 99.99, 1e-3]):
+            got = P.sharded_percentiles(lambda: P.local_minmax_numpy(mine), lambda lo, hi, b: P.local_hist_numpy(mine, lo, hi, b),
+                                        mine.shape[0], m, pcts)
+            want = np.percentile(a, pcts, axis=0)
+            assert got.shape == np.shape(want) and np.array_equal(got, want, equal_nan=True), (rank, pcts)
+        Path(out_dir, f'ok{rank}').write_text('ok')
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_percentiles_equal_numpy_on_the_union_of_the_shards(tmp_path, world):
+    """hallthrusterpem_amd.percentiles.sharded_percentiles: histograms all-reduced level by level (MIN / MAX of the keys, SUM of
+    the counts) until every wanted rank's range is one key -- np.percentile of ALL rows bit for bit on every rank, with a
+    numpy restatement of the device histogram as the local operation (the device kernel is held to it in test_quantiles.py)."""
+    mp.spawn(_percentile_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f'ok{r}').exists() for r in range(world))

@@ -80,3 +80,80 @@ def test_percentile_bands_of_a_forward_uq_campaign():
     for k, v in bands.items():
         assert np.array_equal(v.cpu().numpy(), np.percentile(out[k].cpu().numpy(), [5.0, 50.0, 95.0], axis=0), equal_nan=True)
     assert bool((bands['j_ion'][0] <= bands['j_ion'][1]).all() and (bands['j_ion'][1] <= bands['j_ion'][2]).all())
+
+
+def test_range_histogram_and_key_minmax_equal_their_numpy_restatement():
+    """pem_key_minmax_f64_dev / pem_range_hist_f64_dev (the local operations of the multi-rank percentiles) against
+    percentiles.local_minmax_numpy / local_hist_numpy -- the restatement the gloo tests run the level logic on."""
+    import torch
+    from hallthrusterpem_amd import percentiles as P
+    rng = np.random.default_rng(8)
+    for n, m in ((5000, 1), (4000, 7), (3000, 91), (2000, 200), (0, 5)):
+        a = rng.lognormal(0.0, 3.0, (n, m)) * rng.choice([-1.0, 1.0], (n, m))
+        if n:
+            a[::9, 0] = np.nan
+            a[1::9, m - 1] = -np.inf
+        cols = P.DeviceColumns(torch.from_numpy(a).cuda())
+        kmin, kmax, nan = cols.minmax()
+        wmin, wmax, wnan = P.local_minmax_numpy(a)
+        assert np.array_equal(kmin, wmin) and np.array_equal(kmax, wmax) and np.array_equal(nan, wnan)
+        if not n:
+            continue
+        keys = np.sort(P.key_of(a[~np.isnan(a)]))
+        for nr, bins in ((1, 64), (2, 32), (4, 16), (6, 8)):
+            lo = keys[rng.integers(0, keys.size, (m, nr))]
+            hi = np.maximum(lo, keys[rng.integers(0, keys.size, (m, nr))])
+            hi[0, 0] = lo[0, 0]                                  # a single-key range
+            if nr > 1:
+                hi[0, 1] = lo[0, 1] + np.uint64(bins - 1)        # fewer keys than bins: every key its own bin
+            got = cols.hist(lo, hi, bins)
+            assert np.array_equal(got, P.local_hist_numpy(a, lo, hi, bins)), (n, m, nr)
+
+
+def test_sharded_percentiles_on_one_rank_equal_numpy():
+    import torch
+    from hallthrusterpem_amd.percentiles import column_percentiles_sharded
+    rng = np.random.default_rng(9)
+    a = rng.lognormal(0.0, 3.0, (200_000, 91)) * rng.choice([-1.0, 1.0], (200_000, 91))
+    a[rng.random(200_000) < 0.2, 3] = 1e-20
+    a[5, 7] = np.nan
+    d = torch.from_numpy(a).cuda()
+    for pcts in ([25.0, 75.0], [5.0, 50.0, 95.0], 50.0):
+        assert np.array_equal(column_percentiles_sharded(d, pcts), np.percentile(a, pcts, axis=0), equal_nan=True)
+    s = torch.from_numpy(a[:, 0].copy()).cuda()
+    assert column_percentiles_sharded(s, [10.0, 90.0]).shape == (2,) and np.array_equal(column_percentiles_sharded(s, [10.0, 90.0]), np.percentile(a[:, 0], [10.0, 90.0]))
+    wide = torch.from_numpy(rng.standard_normal((3000, 300))).cuda()
+    assert np.array_equal(column_percentiles_sharded(wide, [50.0]), np.percentile(wide.cpu().numpy(), [50.0], axis=0))
+
+
+def _two_rank_worker(rank, world, port, out_dir):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)            # (both ranks share this box's one GPU: gloo collectives)
+    try:
+        from hallthrusterpem_amd import drivers
+        from hallthrusterpem_amd.percentiles import column_percentiles_sharded
+        n = 400_001
+        lo, hi = (0, 150_000) if rank == 0 else (150_000, n)
+        out = drivers.forward_uq(n, seed=6, keep_profile=True, rank=0, world=1)          # the whole campaign, for the expected values
+        mine = {k: out[k][lo:hi].contiguous() for k in ('j_ion', 'T_c')}
+        for k, pcts in (('j_ion', [5.0, 50.0, 95.0]), ('T_c', [25.0, 75.0])):
+            got = column_percentiles_sharded(mine[k], pcts)
+            assert np.array_equal(got, np.percentile(out[k].cpu().numpy(), pcts, axis=0), equal_nan=True), (rank, k)
+        open(os.path.join(out_dir, f'ok{rank}'), 'w').write('ok')
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_sharing_the_gpu_get_the_percentiles_of_the_whole_campaign(tmp_path):
+    """The multi-rank path end to end with the DEVICE histograms: two processes hold 150 000 and 250 001 samples of one
+    forward-UQ campaign, all-reduce their counts level by level and both arrive at np.percentile of all 400 001 samples."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / 'ok0').exists() and (tmp_path / 'ok1').exists()
