@@ -10,7 +10,8 @@ pytestmark = pytest.mark.gpu
 def _check(a, pcts):
     import torch
     from hallthrusterpem_amd.drivers import column_percentiles
-    want = np.percentile(a, pcts, axis=0)
+    with np.errstate(invalid='ignore'):                       # (inf - inf inside numpy's interpolation of a column of infinities)
+        want = np.percentile(a, pcts, axis=0)
     got = column_percentiles(torch.from_numpy(np.ascontiguousarray(a)).cuda(), pcts).cpu().numpy()
     assert got.shape == want.shape
     assert np.array_equal(got, want, equal_nan=True), (np.abs(got - want).max(), a.shape, pcts)
