@@ -52,6 +52,7 @@ SIGNATURES = {
     'pem_sparse_grid_values_f64_dev': (C.c_int, [_sz, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _sz, _dp, _sz, _dp]),
     'pem_key_minmax_f64_dev': (C.c_int, [_sz, C.c_int, _dp, _sz, _dp, _dp, _dp, _dp]),
     'pem_range_hist_f64_dev': (C.c_int, [_sz, C.c_int, _dp, _sz, C.c_int, _dp, _dp, C.c_int, _dp, _dp]),
+    'pem_range_narrow_dev': (C.c_int, [C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp]),
     'pem_quantiles_f64_dev': (C.c_int, [_sz, C.c_int, _dp, _sz, C.c_int, _dp, _dp, _dp, _dp, _dp]),
     'pem_sobol_partial_f64_dev': (C.c_int, [_sz, C.c_int, _sz, _dp, _dp, _dp, _dp, C.c_int, _dp]),
     'pem_coupled_f32_dev': (C.c_int, [_sz, C.c_float, C.c_float, _dp, _sz, _dp, _sz, _dp, _dp]),

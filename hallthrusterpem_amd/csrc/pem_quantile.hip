@@ -660,6 +660,29 @@ __global__ __launch_bounds__(QBLOCK) void range_hist_kernel(long long n, int m, 
     }
 }
 
+// One level's decision on the device (one wave per range): the bin of the all-reduced histogram that holds the wanted rank,
+// and the keys of that bin -- the inverse of range_scale's map, as percentiles.bin_interval states it -- become the next range.
+__global__ __launch_bounds__(64) void range_narrow_kernel(int bins, const unsigned* __restrict__ hist, u64* __restrict__ klo,
+                                                           u64* __restrict__ khi, long long* __restrict__ resid) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const u64 lo = klo[i], hi = khi[i];
+    if (lo >= hi) return;                                     // already one key (or an empty column)
+    const Found f = find_bin(hist + (size_t)i * bins, bins, (u64)resid[i], lane);
+    if (lane != 0) return;
+    const RangeScale q = range_scale(lo, hi, bins);
+    const u64 b = (u64)f.bin, two32 = 1ull << 32;
+    const u64 d_lo = q.identity ? b : (b * two32 + q.mult - 1) / q.mult;
+    const u64 d_hi = q.identity ? b : ((b + 1) * two32 + q.mult - 1) / q.mult - 1;
+    const bool last = d_hi >= ((hi - lo) >> q.shift);
+    u64 nlo = lo + (d_lo << q.shift);
+    u64 nhi = last ? hi : lo + (((d_hi + 1) << q.shift) - 1);
+    if (nlo < lo) nlo = lo;
+    if (nhi > hi) nhi = hi;
+    klo[i] = nlo;
+    khi[i] = nhi;
+    resid[i] -= (long long)f.before;
+}
+
 __global__ void export_minmax_kernel(const Column* __restrict__ col, int m, u64* kmin, u64* kmax, int* has_nan) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < m) {
@@ -885,6 +908,17 @@ extern "C" int pem_range_hist_f64_dev(size_t n, int m, const double* data, size_
     else R_BY_NR(4);
 #undef R_BY_NR
 #undef R_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return PEM_OK;
+}
+
+extern "C" int pem_range_narrow_dev(int n_ranges, int bins, const uint32_t* hist, uint64_t* klo, uint64_t* khi, int64_t* resid,
+                                    pem_stream_t stream) {
+    if (n_ranges < 1 || bins < 1) return pem::fail(PEM_ERR_INVALID_ARG, "pem_range_narrow: need ranges and bins");
+    if (!hist || !klo || !khi || !resid) return pem::fail(PEM_ERR_INVALID_ARG, "pem_range_narrow: NULL array");
+    if (int rc = pem::check_device()) return rc;
+    hipLaunchKernelGGL(range_narrow_kernel, dim3((unsigned)n_ranges), dim3(64), 0, static_cast<hipStream_t>(stream), bins,
+                       (const unsigned*)hist, (u64*)klo, (u64*)khi, (long long*)resid);
     HIP_TRY(hipGetLastError());
     return PEM_OK;
 }

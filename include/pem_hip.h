@@ -279,6 +279,10 @@ int pem_key_minmax_f64_dev(size_t n, int m, const double* data, size_t ld, uint6
                            pem_stream_t stream);
 int pem_range_hist_f64_dev(size_t n, int m, const double* data, size_t ld, int nr, const uint64_t* klo, const uint64_t* khi,
                            int bins, uint32_t* hist, pem_stream_t stream);
+/* One level's decision, on the device: for each of n_ranges ranges the bin of hist[range][bins] (the all-reduced counts) that
+ * holds resid[range], then klo / khi <- the keys of that bin and resid <- the rank inside it; ranges with klo >= khi are left. */
+int pem_range_narrow_dev(int n_ranges, int bins, const uint32_t* hist, uint64_t* klo, uint64_t* khi, int64_t* resid,
+                         pem_stream_t stream);
 
 /* ---- fused Monte-Carlo evaluation -----------------------------------------------------------------
  * sample_inputs + predict of scripts/gen_data.py:238-239 in ONE launch: the 15 coupled inputs of global samples

@@ -120,7 +120,8 @@ def test_sharded_percentiles_on_one_rank_equal_numpy():
     a[5, 7] = np.nan
     d = torch.from_numpy(a).cuda()
     for pcts in ([25.0, 75.0], [5.0, 50.0, 95.0], 50.0):
-        assert np.array_equal(column_percentiles_sharded(d, pcts), np.percentile(a, pcts, axis=0), equal_nan=True)
+        for on_device in (True, False):      # the levels decided on the device (pem_range_narrow_dev) and by the numpy restatement
+            assert np.array_equal(column_percentiles_sharded(d, pcts, on_device=on_device), np.percentile(a, pcts, axis=0), equal_nan=True)
     s = torch.from_numpy(a[:, 0].copy()).cuda()
     assert column_percentiles_sharded(s, [10.0, 90.0]).shape == (2,) and np.array_equal(column_percentiles_sharded(s, [10.0, 90.0]), np.percentile(a[:, 0], [10.0, 90.0]))
     wide = torch.from_numpy(rng.standard_normal((3000, 300))).cuda()
