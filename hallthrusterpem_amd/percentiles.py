@@ -127,11 +127,12 @@ def _all_reduce(arr, op, group):
     return t.cpu().numpy()
 
 
-def sharded_percentiles(local_minmax, local_hist, n_local: int, m: int, percentiles, group=None, device_levels=None, cols=None):
+def sharded_percentiles(local_minmax, local_hist, n_local: int, m: int, percentiles, group=None, device_levels=None):
     """Percentiles (method 'linear') of the union of all ranks' rows, per column: array (len(percentiles), m), the same on every rank.
 
     local_minmax() -> (kmin[m], kmax[m] uint64 keys, has_nan[m]) of this rank's rows (kmin > kmax: none);
-    local_hist(klo[m][nr], khi[m][nr] uint64, bins) -> counts [m][nr][bins] of this rank's keys inside the ranges, nr in {1, 2, 4, 6}."""
+    local_hist(klo[m][nr], khi[m][nr] uint64, bins) -> counts [m][nr][bins] of this rank's keys inside the ranges, nr in {1, 2, 4, 6};
+    device_levels(ranks[nr], klo0[m], khi0[m]) -> keys [m][nr]: the whole level loop done elsewhere (on the device), optional."""
     import torch.distributed as dist
     n = int(_all_reduce(np.array([n_local], dtype=np.int64), dist.ReduceOp.SUM, group)[0])
     if n == 0:
@@ -151,8 +152,7 @@ def sharded_percentiles(local_minmax, local_hist, n_local: int, m: int, percenti
         ranks = np.stack([rank_prev[sel], rank_next[sel]], axis=1).reshape(-1)    # [prev0, next0, prev1, ...]
         nr = {2: 2, 4: 4, 6: 6}[ranks.size]
         if device_levels is not None:                                             # the same levels, resident on the device
-            cols._klo0, cols._khi0 = np.where(empty, U64(1), smin).astype(U64), np.where(empty, U64(0), smax).astype(U64)
-            vals = value_of(device_levels(ranks))
+            vals = value_of(device_levels(ranks, np.where(empty, U64(1), smin).astype(U64), np.where(empty, U64(0), smax).astype(U64)))
             for i, qi in enumerate(range(sel.start, sel.stop)):
                 out[qi] = lerp(vals[:, 2 * i], vals[:, 2 * i + 1], gamma[qi])
             continue
@@ -226,18 +226,18 @@ class DeviceColumns:
         return out
 
 
-def _device_levels(cols, ranks, group):
+def _device_levels(cols, ranks, klo0, khi0, group):
     """The level loop with ranges, counts and decisions resident on the device (`pem_range_hist_f64_dev` -> all-reduce ->
     `pem_range_narrow_dev`): per level one streaming pass, one collective on a device tensor and one flag read -- no histogram
-    crosses PCIe.  `ranks`: (nr,) wanted ranks of this pass; returns the (m, nr) keys.  One chunk of columns (m <= 256)."""
+    crosses PCIe.  `ranks`: (nr,) wanted ranks of this pass, klo0 / khi0: (m,) the columns' global key range; returns the (m, nr) keys.  One chunk of columns (m <= 256)."""
     import torch
     import torch.distributed as dist
     lib, dev, m, nr = cols.lib.load(), cols.flat.device, cols.m, ranks.size
     bins = 1
     while 2 * bins * m * nr <= LDS_WORDS and 2 * bins <= 4096:
         bins *= 2
-    klo = torch.from_numpy(np.repeat(cols._klo0[:, None], nr, axis=1).view(np.int64).copy()).to(dev)
-    khi = torch.from_numpy(np.repeat(cols._khi0[:, None], nr, axis=1).view(np.int64).copy()).to(dev)
+    klo = torch.from_numpy(np.repeat(klo0[:, None], nr, axis=1).view(np.int64).copy()).to(dev)
+    khi = torch.from_numpy(np.repeat(khi0[:, None], nr, axis=1).view(np.int64).copy()).to(dev)
     resid = torch.from_numpy(np.broadcast_to(ranks, (m, nr)).astype(np.int64).copy()).to(dev)
     hist = torch.empty((m, nr, bins), dtype=torch.int32, device=dev)
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
@@ -265,6 +265,6 @@ def column_percentiles_sharded(a, percentiles, group=None, on_device: bool = Tru
     """`np.percentile(concatenation of every rank's `a`, percentiles, axis=0)`, bit for bit, on every rank: `a` is this rank's
     (n_local, ...) CUDA tensor (n_local may be 0 on some ranks).  Returns a numpy array (len(percentiles), ...)."""
     cols = DeviceColumns(a)          # (more than 256 columns: the local operations go through them 256 at a time)
-    levels = (lambda ranks: _device_levels(cols, ranks, group)) if (on_device and cols.m <= 256) else None
-    res = sharded_percentiles(cols.minmax, cols.hist, cols.n, cols.m, percentiles, group=group, device_levels=levels, cols=cols)
+    levels = (lambda ranks, klo0, khi0: _device_levels(cols, ranks, klo0, khi0, group)) if (on_device and cols.m <= 256) else None
+    res = sharded_percentiles(cols.minmax, cols.hist, cols.n, cols.m, percentiles, group=group, device_levels=levels)
     return res.reshape(res.shape[:-1] + cols.trailing) if cols.trailing else res[..., 0]
