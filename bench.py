@@ -386,6 +386,19 @@ def main():
                   'frac_of_peak': batch.bytes_per_eval * n / (sm * 1e-3) / 1e9 / HBM_PEAK_GBS,
                   'note': 'one batch re-evaluated every step: its 150 MB of inputs stay in the 256 MB Infinity Cache; NOT the headline'}
 
+    # what the memory system gives its BEST-CASE write stream of the shard's output size on this box (torch fill_ over the
+    # batches' profile buffers in rotation -- they are no longer needed; an address-ordered one-shot fill, 6.4-6.9 TB/s, where a
+    # store-only kernel with this kernel's 46-KB-per-wave pattern reaches 5.3-5.5: DESIGN.md section 6)
+    write_stream = None
+    if not multi and nb > 1 and not (args.no_profile or args.mixed) and not args.no_single_batch:
+        k = [0]
+
+        def fill():
+            batches[k[0] % nb].j_ion.fill_(0.0)
+            k[0] += 1
+        fm, _ = event_times(fill, 40)
+        write_stream = batches[0].j_ion.numel() * 8 / (fm * 1e-3) / 1e9
+
     if rank == 0:
         bytes_per_launch = batch.bytes_per_eval * n
         achieved = bytes_per_launch / (kern_mean_ms * 1e-3) / 1e9
@@ -413,7 +426,9 @@ def main():
                                             f'launch size, gfx950 corrections applied); not measured in this run') if traffic else None,
                          'kernel': 'plume_r1_kernel<L,COUPLED,JMODE>', 'kernel_ms_mean': kern_mean_ms,
                          'kernel_ms_min': kern_min_ms, 'bytes_per_eval': batch.bytes_per_eval,
-                         'bytes_per_launch': bytes_per_launch},
+                         'bytes_per_launch': bytes_per_launch,
+                         'write_stream_GBs': write_stream,
+                         'frac_of_write_stream': (achieved / write_stream) if write_stream else None},
         }
         if world == 1 and not multi and args.full_config_samples > 0 and not (args.no_profile or args.mixed):
             del batch, batches, b
