@@ -58,6 +58,17 @@ __global__ __launch_bounds__(256) void writer_affinity(f64x2* __restrict__ out, 
     const f64x2 v = {1.0 + lane, 2.0};
     out[(c * 4 + (threadIdx.x >> 6)) * 64 + lane] = v;
 }
+// E7: one-shot, 1 KB per wave; XCD x (= b mod 8) owns the x-th eighth of the buffer and writes it as S interleaved sequential
+// streams: its j-th workgroup (j = b / 8) appends a 4-KB chunk to stream j mod S.  S = 1 is E5's third mode.
+__global__ __launch_bounds__(256) void writer_streams(f64x2* __restrict__ out, long long nblocks, int S) {
+    const int lane = threadIdx.x & 63;
+    const long long b = blockIdx.x, x = b & 7, j = b >> 3, per_xcd = nblocks / 8, per_stream = per_xcd / S;
+    const long long st = j % S, pos = j / S;
+    if (pos >= per_stream) return;
+    const long long c = x * per_xcd + st * per_stream + pos;
+    const f64x2 v = {1.0 + lane, 2.0};
+    out[(c * 4 + (threadIdx.x >> 6)) * 64 + lane] = v;
+}
 // E2: one-shot, a workgroup owns a region of 4 * ppt pieces; its four waves interleave piece by piece (wave w: pieces w, w + 4, ...)
 __global__ __launch_bounds__(256) void writer_interleaved(f64x2* __restrict__ out, long long pieces_total, int ppt) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -147,6 +158,13 @@ int main() {
                 snprintf(what, sizeof what, "E5 one-shot 1 KB per wave, %s", names[mode]);
                 timeit([&](int i) { hipLaunchKernelGGL(writer_affinity, dim3((unsigned)nb8), dim3(256), 0, 0, buf[i % NB], nb8, mode); }, what, nb8 * 4096.0);
             }
+        }
+        for (int S : {1, 2, 4, 8, 16, 64, 256}) {
+            const long long nb8 = nblocks / 8 * 8;
+            char what[160];
+            snprintf(what, sizeof what, "E7 one-shot 1 KB per wave, every XCD writes its eighth as %3d interleaved sequential streams", S);
+            timeit([&](int i) { hipLaunchKernelGGL(writer_streams, dim3((unsigned)nb8), dim3(256), 0, 0, buf[i % NB], nb8, S); }, what,
+                   (double)(nb8 / 8 / S * S * 8) * 4096.0);
         }
         for (int ppt : {2, 3}) {     // E3: one-shot, 2 and 3 KB per wave (adjacent pieces)
             const long long use = pieces / ppt * ppt, tiles = use / ppt;
