@@ -341,9 +341,10 @@ __global__ __launch_bounds__(QBLOCK) void hist2_kernel(long long n, int m, size_
             const u64 k = key_of(x);
             unsigned frac;
             const int b = bin_of(k, sc[j], frac);
+            int hit = -1;                                   // at most one target holds a given bin (deduplicated above): one branch, not NT
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-                if (tb[j][t] == b) atomicAdd(&lds_hist[(c * NT + t) * bins2 + subbin_of(frac, bins2)], 1u);
+            for (int t = 0; t < NT; ++t) hit = tb[j][t] == b ? t : hit;
+            if (hit >= 0) atomicAdd(&lds_hist[(c * NT + hit) * bins2 + subbin_of(frac, bins2)], 1u);
         }
     });
     __syncthreads();
@@ -440,12 +441,13 @@ __global__ __launch_bounds__(QBLOCK) void compact_kernel(long long n, int m, siz
             const u64 k = key_of(x);
             unsigned frac;
             const int b = bin_of(k, sc[j], frac);
+            const int sb = subbin_of(frac, bins2);
+            int hit = -1;                                   // list owners have distinct (bin, sub-bin) pairs: at most one matches
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                if (tb1[j][t] == b && subbin_of(frac, bins2) == tb2[j][t]) {
-                    Target& T = tg[c * NT + t];
-                    cand[T.offset + atomicAdd(&T.cursor, 1ull)] = k;
-                }
+            for (int t = 0; t < NT; ++t) hit = (tb1[j][t] == b && tb2[j][t] == sb) ? t : hit;
+            if (hit >= 0) {
+                Target& T = tg[c * NT + hit];
+                cand[T.offset + atomicAdd(&T.cursor, 1ull)] = k;
             }
         }
     });
