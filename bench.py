@@ -5,13 +5,17 @@
 
 One "step" = one pass of the hot path over one batch of synthetic Monte-Carlo samples already resident in HBM: this
 rank's shard of BASELINE.json configs[2] (1e7 coupled samples sharded over 8 GPUs = 1.25e6 samples per GPU; the same
-per-GPU shard at every N, so scaling is weak) evaluated by `pem_coupled_f64_dev`, followed at N > 1 by the path's only
-exchange, the RCCL all-gather of the reduced QoIs (V_cc, div_angle, T_c).  Steps rotate over `--batches` (default 8)
+per-GPU shard at every N, so scaling is weak) evaluated by `pem_coupled_tiled_f64_dev` (inputs tile-interleaved; `--layout soa`:
+`pem_coupled_f64_dev`, 15 arrays -- 2-4 % slower, profiles/grid_modes_r03.txt), followed at N > 1 by the path's only
+exchange, the RCCL all-gather of the reduced QoIs (V_cc, div_angle, T_c).  Consecutive launches are dealt onto `--streams`
+(default 2) HIP streams: every step is a complete launch over its own batch, but launch i+1 may start on the wave slots the
+tail of launch i leaves idle (3-7 % per step); `config.single_stream` carries the one-stream rate of the same steps, and the
+`roofline` object quotes the duration of ISOLATED launches, as before.  Steps rotate over `--batches` (default 8)
 batches with their own inputs and result buffers -- 8.7 GB, the footprint of the whole config -- because re-evaluating ONE
 batch every step is helped by the 256 MB Infinity Cache (its 150 MB of inputs never leave it: measured 191 against 209-225
 us per launch, tools/mall_probe.py); the cache-assisted rate of a single re-evaluated batch, the number rounds 1 and early
 round 2 reported, is carried as `config.single_batch_rerun` for comparison and is not `value`.  At N > 1 the shard is cut into `--chunks`
-pieces and the all-gather of piece k runs beside the evaluation of piece k+1 (hallthrusterpem_amd.distributed.
+(default 2, equal, on tile boundaries) pieces and the all-gather of piece k runs beside the evaluation of piece k+1 (hallthrusterpem_amd.distributed.
 ChunkedGather), so a single campaign overlaps its own exchange; `--gather once` is the one-collective-per-campaign
 schedule, `--gather none` skips the exchange, `--gather full` moves the 91-point profiles.
 
@@ -60,7 +64,7 @@ def synth_inputs(batch, seed, rank, which=0):
     for lo in range(0, batch.n, chunk):
         hi = min(batch.n, lo + chunk)
         u = torch.rand((15, hi - lo), dtype=torch.float64, device=batch.device, generator=g)
-        x = batch.inputs[:, lo:hi]
+        x = torch.empty_like(u)
         x[0] = 10 ** (u[0] * 4 - 8)                  # P_b      Torr, log-uniform over the domain (yml:9-17)
         x[1] = u[1] * 200 + 200                      # V_a      V
         x[2] = u[2] * 4 + 1                          # T_e      eV
@@ -76,7 +80,8 @@ def synth_inputs(batch, seed, rank, which=0):
         x[12] = 10 ** (u[12] * 4 + 18)               # c4
         x[13] = 10 ** (u[13] * 4 + 14)               # c5
         x[14] = u[14] * 7e-20 + 51e-20               # sigma_cex
-        del u
+        batch.load_soa(x, lo)                        # rows -> the batch's own input layout ('soa' or 'tile')
+        del u, x
 
 
 def host_cpu_share():
@@ -120,16 +125,37 @@ def cpu_baseline(target_seconds=2.5):
                                           'measured in the build container (8 vCPU Xeon @2.1 GHz); the reference cannot travel to this host'}}
 
 
-def read_committed_traffic(n):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), if they were taken at this n."""
+def kernel_source_hash():
+    """Digest of the translation unit the coupled kernel is compiled from and of the headers it includes: what a committed
+    counter measurement has to carry (`kernel_srchash`) to be replayed as this run's `roofline.traffic`."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = ROOT / 'hallthrusterpem_amd' / 'csrc'
+    for f in [csrc / 'pem_kernels.hip'] + sorted(csrc.glob('*.h')) + [ROOT / 'include' / 'pem_hip.h']:
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def read_committed_traffic(n, layout='soa'):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/traffic_r*.json) -- only a record taken at
+    this launch size, for this input layout, FROM THE KERNEL SOURCES IN THE TREE (`kernel_srchash`): a kernel edit after the
+    counters were collected drops the replay (traffic: null) instead of quoting the old ratio.
+    Returns (bytes, file name, why-not)."""
+    want = kernel_source_hash()
+    stale = None
     for f in sorted((ROOT / 'profiles').glob('traffic_r*.json'), reverse=True):
         try:
             rec = json.loads(f.read_text())
-            if int(rec.get('samples_per_launch', -1)) == int(n):
-                return float(rec['hbm_bytes_per_launch']), f.name
+            if int(rec.get('samples_per_launch', -1)) != int(n) or rec.get('layout', 'soa') != layout:
+                continue
+            if rec.get('kernel_srchash') != want:
+                stale = stale or f'{f.name} was measured on other kernel sources (kernel_srchash {rec.get("kernel_srchash")}, tree {want})'
+                continue
+            return float(rec['hbm_bytes_per_launch']), f.name, None
         except Exception:
             continue
-    return None, None
+    return None, None, stale or 'no committed counter measurement of this launch size'
 
 
 def event_times(fn, reps):
@@ -145,11 +171,11 @@ def event_times(fn, reps):
     return sum(ms) / len(ms), ms[0]
 
 
-def full_config_pass(n, seed, lanes):
+def full_config_pass(n, seed, lanes, layout='soa'):
     """configs[2] whole: n = 1e7 coupled samples as one launch on this GPU (N = 1 only)."""
     import torch
     from hallthrusterpem_amd.batch import CoupledBatch
-    b = CoupledBatch(n, profile=True, thruster_qoi=False)
+    b = CoupledBatch(n, profile=True, thruster_qoi=False, layout=layout)
     synth_inputs(b, seed, 0)
     for _ in range(2):
         b.run()
@@ -180,6 +206,9 @@ def fp32_report(n, seed):
 def spawn_ranks(args_list, n):
     """`bench.py --gpus N` outside torch.distributed.run: start the N ranks as a child process (nothing in THIS process
     has touched the GPU) and pass its stdout -- the one JSON line of rank 0 -- and exit code through."""
+    from hallthrusterpem_amd import build as hip_build
+    if 'PEM_HIP_LIB' not in os.environ and hip_build.needs_build() and hip_build.have_hipcc():
+        hip_build.build()                            # once, here: N ranks would otherwise each find the stale stamp
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
@@ -203,8 +232,19 @@ def main():
     ap.add_argument('--gather', choices=['qoi', 'once', 'full', 'none'], default='qoi',
                     help='N>1 exchange: qoi = reduced QoIs (24 B/sample) in --chunks overlapped pieces; once = the same in one '
                          'collective per campaign; full = the 91-point profiles; none = no exchange')
-    ap.add_argument('--chunks', type=int, default=4, help='pieces a shard is cut into at N>1 so that the all-gather of piece k '
+    ap.add_argument('--chunk-align', choices=['round', 'tile'], default='tile',
+                    help='tile: equal pieces on 64-sample boundaries (default: measured as fast as one launch, 312 512-sample pieces '
+                         'run at 214-217 us per step against 213-218); round: every piece a whole number of rounds of the resident '
+                         'grid (measured 4 %% slower on one stream, equal on two: profiles/schedule_r03.txt)')
+    ap.add_argument('--chunks', type=int, default=2, help='pieces a shard is cut into at N>1 so that the all-gather of piece k '
                                                           'overlaps the evaluation of piece k+1')
+    ap.add_argument('--layout', choices=['soa', 'tile'], default='tile',
+                    help="input layout: soa = 15 arrays (pem_coupled_f64_dev); tile = [tiles][15][64] blocks (pem_coupled_tiled_f64_dev)")
+    ap.add_argument('--streams', type=int, default=2, choices=[1, 2, 4],
+                    help='consecutive launches (steps; at N > 1 the chunk launches of the pipeline) are dealt onto this many HIP '
+                         'streams, so that launch i+1 fills the wave slots the tail of launch i leaves idle; 1 = every launch waits for '
+                         'the one before (rounds 1-2).  The roofline object always quotes the duration of ISOLATED launches; the '
+                         'one-stream rate of the same run is carried as config.single_stream')
     ap.add_argument('--no-single-batch', action='store_true', help='skip the cache-assisted single-batch comparison run (profiling: every launch is then a rotating one)')
     ap.add_argument('--no-profile', action='store_true', help='reduced-QoI mode: never write j_ion (144 B/eval)')
     ap.add_argument('--mixed', action='store_true', help='fp64 arithmetic, fp32 storage of the profile (508 B/eval)')
@@ -231,7 +271,7 @@ def main():
     import torch.distributed as dist
     from hallthrusterpem_amd import _lib
     from hallthrusterpem_amd.batch import CoupledBatch
-    from hallthrusterpem_amd.distributed import ChunkedGather
+    from hallthrusterpem_amd.distributed import ChunkedGather, launch_rounds
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -266,13 +306,15 @@ def main():
 
     lib = _lib.load()
     _lib.require_device()
+    if args.mixed:
+        args.layout = 'soa'                      # the fp32-profile entry point takes the 15 arrays only
     lanes = lib.pem_set_lanes_per_sample(args.lanes)
     n = args.samples_per_gpu
     # outputs per evaluation exactly as SURVEY section 8d counts them: V_cc, j_ion[91], div_angle, T_c (+ invalid flag)
     nb = max(1, args.batches)
     batches = []
     for k in range(nb):
-        b = CoupledBatch(n, profile=not args.no_profile, mixed=args.mixed, thruster_qoi=False)
+        b = CoupledBatch(n, profile=not args.no_profile, mixed=args.mixed, thruster_qoi=False, layout=args.layout)
         synth_inputs(b, args.seed, rank, k)
         batches.append(b)
     batch = batches[0]
@@ -286,20 +328,43 @@ def main():
     # N > 1: the shard in `chunks` pieces, each piece's QoIs in its own send buffer, its all-gather beside the next piece
     gather_on = multi and args.gather != 'none'
     chunks = 1 if (not gather_on or args.gather in ('once', 'full')) else max(1, args.chunks)
-    pipe = ChunkedGather(n, 3, chunks, batch.device, gather=gather_on and args.gather != 'full') if multi else None
+    # ... cut on whole rounds of the persistent grid this launch takes (a round that is partly filled costs a whole one)
+    mode = 0 if args.no_profile else (2 if args.mixed else 1)
+    cus, wg_per_cu = _lib.coupled_occupancy(mode)
+    round_samples, shard_rounds = launch_rounds(n, cus, wg_per_cu, memory_bound=mode != 0)
+    if args.chunk_align == 'tile':
+        round_samples = None                        # round 2's cut: equal pieces on 64-sample tile boundaries
+    pipe = ChunkedGather(n, 3, chunks, batch.device, gather=gather_on and args.gather != 'full',
+                         round_samples=round_samples) if multi else None
     full_recv = torch.empty((world * n, batch.j_ion.shape[1]), dtype=batch.j_ion.dtype, device=batch.device) \
         if (gather_on and args.gather == 'full' and batch.profile) else None
     pending_full = [None]
     use_gather = [True]
 
+    # --streams S: launches are dealt onto S streams in turn.  A given (batch, chunk) always lands on the same stream (the
+    # batches in rotation and hence the launches per cycle are a multiple of S), so stream order alone keeps a launch from
+    # overwriting results an earlier one is still producing: no events between the streams, which would serialise them.
+    if args.streams > 1 and nb % args.streams:
+        raise SystemExit('bench.py: --batches must be a multiple of --streams (a batch is then always evaluated on the same stream)')
+    side = [torch.cuda.Stream(device=batch.device) for _ in range(args.streams)] if args.streams > 1 else None
+    launches = [0]
+
+    def launch(cur, **kw):
+        if side is None:
+            cur.run(**kw)
+            return
+        st = side[launches[0] % len(side)]
+        launches[0] += 1
+        cur.run(stream=st, **kw)
+
     def step():
         cur = next_batch()
         if pipe is None:
-            cur.run()
+            launch(cur)
             return
         if not use_gather[0]:
             for first, count in pipe.bounds:
-                cur.run(first=first, count=count)
+                launch(cur, first=first, count=count)
             return
         if full_recv is not None:
             if pending_full[0] is not None:
@@ -307,7 +372,7 @@ def main():
             cur.run()
             pending_full[0] = dist.all_gather_into_tensor(full_recv, cur.j_ion, async_op=True)
         else:
-            pipe.step(lambda first, count, out_rows: cur.run(first=first, count=count, qoi_out=out_rows))
+            pipe.step(lambda first, count, out_rows: cur.run(first=first, count=count, qoi_out=out_rows), streams=side)
 
     def drain():
         if pipe is not None:
@@ -339,6 +404,12 @@ def main():
     for _ in range(args.warmup):
         step()
     elapsed = timed(args.steps)
+    # the same steps with every launch waiting for the one before (what rounds 1-2 timed), for the record
+    elapsed_one_stream = None
+    if side is not None and not multi:
+        keep, side = side, None
+        elapsed_one_stream = timed(args.steps)
+        side = keep
     # N > 1: also the gather-free rate of the same shards (reported beside `value`, SURVEY.md section 8e "report both")
     elapsed_nogather = None
     if gather_on:
@@ -351,6 +422,7 @@ def main():
     if gather_on and full_recv is None:
         which = counter[0] % nb                                 # the batch the next step takes
         step()
+        torch.cuda.synchronize()                                # (the chunks may have run on side streams)
         got = pipe.assemble()                                   # [3][world * n], global order
         ok = True
         scratch = batches[which]
@@ -402,7 +474,8 @@ def main():
     if rank == 0:
         bytes_per_launch = batch.bytes_per_eval * n
         achieved = bytes_per_launch / (kern_mean_ms * 1e-3) / 1e9
-        traffic, traffic_file = read_committed_traffic(n) if not (args.no_profile or args.mixed) else (None, None)
+        traffic, traffic_file, traffic_why = read_committed_traffic(n, args.layout) if not (args.no_profile or args.mixed) \
+            else (None, None, 'counter passes are kept for the fp64-profile launch only')
         gather_desc = {'qoi': f'reduced QoIs (24 B/sample), {len(pipe.bounds) if pipe else 1} chunks per step, each all-gather overlapped with the next chunk\'s evaluation',
                        'once': 'reduced QoIs (24 B/sample), one all-gather per step, overlapped with the next step',
                        'full': '91-point profiles, one all-gather per step, overlapped with the next step'}.get(args.gather, 'none')
@@ -414,7 +487,15 @@ def main():
                                    'BASELINE configs[2] shard (1e7 samples / 8 GPUs), 91 angles, R=1 at 1.0 m',
                        'samples_per_gpu': n, 'global_samples_per_step': world * n, 'seed': args.seed,
                        'TORR_2_PA': 133.322, 'lanes_per_sample': lanes, 'profile_written': not args.no_profile,
-                       'batches_rotated': nb, 'single_batch_rerun': single,
+                       'batches_rotated': nb, 'input_layout': args.layout, 'streams': args.streams,
+                       'single_stream': ({'ms_per_step': 1e3 * elapsed_one_stream / args.steps, 'value': world * n * args.steps / elapsed_one_stream,
+                                          'note': 'the same steps on ONE stream, every launch waiting for the one before'}
+                                         if elapsed_one_stream else None),
+                       'single_batch_rerun': single,
+                       'launch_rounds': {'samples_per_round': round_samples or launch_rounds(n, cus, wg_per_cu, mode != 0)[0],
+                                         'rounds_per_shard': shard_rounds, 'compute_units': cus, 'workgroups_per_cu': wg_per_cu,
+                                         'chunks': [list(b) for b in pipe.bounds] if pipe else [[0, n]],
+                                         'chunk_align': args.chunk_align},
                        'gather': gather_desc if gather_on else 'none',
                        'gathered_qoi_verified': verified,
                        'value_without_gather': (world * n * args.steps / elapsed_nogather) if elapsed_nogather else None,
@@ -423,17 +504,24 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'traffic_source': (f'replayed from profiles/{traffic_file} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this '
-                                            f'launch size, gfx950 corrections applied); not measured in this run') if traffic else None,
+                                            f'launch size, gfx950 corrections applied; same kernel sources, kernel_srchash {kernel_source_hash()}); '
+                                            f'not measured in this run') if traffic else f'none: {traffic_why}',
                          'kernel': 'plume_r1_kernel<L,COUPLED,JMODE>', 'kernel_ms_mean': kern_mean_ms,
                          'kernel_ms_min': kern_min_ms, 'bytes_per_eval': batch.bytes_per_eval,
                          'bytes_per_launch': bytes_per_launch,
+                         'steps_overlapped': ({'streams': args.streams, 'ms_per_step': 1e3 * elapsed / args.steps,
+                                               'achieved': bytes_per_launch * args.steps / elapsed / 1e9,
+                                               'frac': bytes_per_launch * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
+                                               'note': 'algorithmic bytes per step / wall time per step of the timed region: launches on '
+                                                       'alternating streams overlap at their ends, so a step costs less than an isolated launch'}
+                                              if (side is not None and not multi) else None),
                          'write_stream_GBs': write_stream,
                          'frac_of_write_stream': (achieved / write_stream) if write_stream else None},
         }
         if world == 1 and not multi and args.full_config_samples > 0 and not (args.no_profile or args.mixed):
             del batch, batches, b
             torch.cuda.empty_cache()
-            line['config']['full_config'] = full_config_pass(args.full_config_samples, args.seed, lanes)
+            line['config']['full_config'] = full_config_pass(args.full_config_samples, args.seed, lanes, args.layout)
         if args.fp32 and world == 1:
             line['fp32'] = fp32_report(n, args.seed)
         if world == 1 and not args.no_cpu_baseline:

@@ -29,6 +29,8 @@ SIGNATURES = {
     'pem_synchronize': (C.c_int, [_dp]),
     'pem_set_lanes_per_sample': (C.c_int, [C.c_int]),
     'pem_angle_grid': (C.POINTER(C.c_double), []),
+    'pem_persistent_grid': (C.c_int, [_sz, C.c_int, C.c_int, C.c_int, C.POINTER(_sz), C.POINTER(_sz)]),
+    'pem_coupled_occupancy': (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'pem_cathode_f64_dev': (C.c_int, [_sz] + [_dp] * 6 + [_f8, _dp, _dp]),
     'pem_cathode_f64': (C.c_int, [_sz] + [_dp] * 6 + [_f8, _dp]),
     'pem_plume_f64_dev': (C.c_int, [_sz, C.c_int, _dp, _f8] + [_dp] * 10 + [_dp] * 4 + [_dp]),
@@ -39,6 +41,7 @@ SIGNATURES = {
     'pem_thruster_filter_f64_dev': (C.c_int, [_sz, C.c_int, _dp, _dp, _f8, C.c_int, _dp, _dp, _dp, _dp]),
     'pem_coupled_f64_dev': (C.c_int, [_sz, _f8, _f8] + [_dp] * 15 + [_dp] * 7 + [_dp]),
     'pem_coupled_f64': (C.c_int, [_sz, _f8, _f8] + [_dp] * 15 + [_dp] * 7),
+    'pem_coupled_tiled_f64_dev': (C.c_int, [_sz, _f8, _f8, _dp] + [_dp] * 7 + [_dp]),
     'pem_coupled_mixed_dev': (C.c_int, [_sz, _f8, _f8] + [_dp] * 15 + [_dp] * 7 + [_dp]),
     'pem_coupled_loglik_f64_dev': (C.c_int, [_sz, _f8, _f8] + [_dp] * 15 + [C.c_int, C.c_int] + [_dp] * 4 + [_dp] * 5 + [_dp]),
     'pem_coupled_latent_f64_dev': (C.c_int, [_sz, _f8, _f8] + [_dp] * 15 + [C.c_int, C.c_int, _dp, _dp] + [_dp] * 4 + [_dp]),
@@ -59,6 +62,7 @@ SIGNATURES = {
     'pem_saltelli_f32_dev': (C.c_int, [_sz, C.c_uint64, C.c_uint64, C.c_uint32, _dp, _dp, _dp, C.c_int, _dp, C.c_float, C.c_float, _dp, _dp, C.c_int, _dp]),
     'pem_saltelli_f64_dev': (C.c_int, [_sz, C.c_uint64, C.c_uint64, C.c_uint32, _dp, _dp, _dp, C.c_int, _dp, C.c_double, C.c_double, _dp, _dp, C.c_int, _dp]),
     'pem_sample_f64_dev': (C.c_int, [_sz, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _sz, _dp]),
+    'pem_sample_tiled_f64_dev': (C.c_int, [_sz, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _dp]),
     'pem_sample_lhs_f64_dev': (C.c_int, [_sz, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, _dp, _dp, _dp, _dp, _sz, _dp]),
 }
 
@@ -144,6 +148,20 @@ def set_device(index: int):
         torch.cuda.set_device(int(index))
     except ImportError:
         pass
+
+
+def persistent_grid(n: int, cus: int, wg_per_cu: int, memory_bound: bool = True):
+    """(workgroups, samples per round) of a persistent launch over n samples: pure arithmetic, runs without a GPU."""
+    wg, spr = _sz(0), _sz(0)
+    check(load().pem_persistent_grid(int(n), int(cus), int(wg_per_cu), 1 if memory_bound else 0, C.byref(wg), C.byref(spr)))
+    return int(wg.value), int(spr.value)
+
+
+def coupled_occupancy(profile_mode: int = 1):
+    """(compute units, resident workgroups per CU) of the coupled kernel on the current device; needs the GPU."""
+    cus, per = C.c_int(0), C.c_int(0)
+    check(load().pem_coupled_occupancy(int(profile_mode), C.byref(cus), C.byref(per)))
+    return int(cus.value), int(per.value)
 
 
 def require_device():

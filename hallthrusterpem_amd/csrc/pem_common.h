@@ -2,7 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
+#include <cstdint>
 #include <cstdio>
 
 #include "pem_hip.h"
@@ -28,6 +30,42 @@ inline int check_device() {
                     e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
     }
     return PEM_OK;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel; a function-local `static` would set it
+// for the first device a process launches on only, and every later launch on another GPU of the process that asks for more
+// than 64 KB of dynamic LDS would fail.  One of these per kernel instantiation: a bit per device, set after the first
+// successful call on it.  The call is idempotent, so two threads racing through it do no harm (relaxed atomics only keep
+// the flag word itself well defined).
+struct LdsAttrOnce {
+    std::atomic<uint64_t> done{0};
+    hipError_t ensure(const void* kernel, int bytes = 160 * 1024) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        const uint64_t bit = 1ull << (dev & 63);
+        if (done.load(std::memory_order_relaxed) & bit) return hipSuccess;
+        e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e == hipSuccess) done.fetch_or(bit, std::memory_order_relaxed);
+        return e;
+    }
+};
+
+// compute units of the calling thread's current device (cached per device, safe from any thread)
+inline hipError_t device_cus(int* out) {
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    int v = cus[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        e = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return e;
+        cus[dev].store(v, std::memory_order_relaxed);
+    }
+    *out = v;
+    return hipSuccess;
 }
 
 }  // namespace pem

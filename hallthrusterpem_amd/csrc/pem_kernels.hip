@@ -77,6 +77,10 @@ struct PlumeIO {
     const double *m_wgt, *m_y, *m_inv_std;
     double* loglik;
     int n_cond, n_ang;
+    // Where sample g of an input array lives: ptr[(g / 64) * in_tile_stride + g % 64].  64 = plain SoA arrays (every entry
+    // point but one); 15 * 64 = the tile-interleaved layout of pem_coupled_tiled_f64_dev, whose 15 "arrays" are the rows of
+    // one [tiles][15][64] block (R = 1 fast path only: the other plume kernels index the arrays directly).
+    long long in_tile_stride = 64;
 };
 
 struct CoupledIO {
@@ -123,6 +127,7 @@ __device__ __forceinline__ void stream_store1(double v, double* p) {
 template <bool COUPLED>
 __device__ __forceinline__ SampleIn<COUPLED> load_sample(const PlumeIO& io, const CoupledIO& cio, long long gi) {
     SampleIn<COUPLED> v;
+    gi = (gi >> 6) * io.in_tile_stride + (gi & 63);
     v.P_b = stream_load(io.P_b + gi);
     v.c0 = stream_load(io.c0 + gi);
     v.c1 = stream_load(io.c1 + gi);
@@ -1247,7 +1252,7 @@ __global__ __launch_bounds__(BLOCK) void thruster_filter_kernel(long long n, int
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-int g_lanes = 4;
+std::atomic<int> g_lanes{4};
 std::atomic<int> g_device{-1};   // process default of the host-pointer entry points (pem_init); -1: the calling thread's
 
 // Host-pointer entry points run on the device given to pem_init, whichever thread calls them: a new thread's current
@@ -1280,61 +1285,99 @@ size_t balanced_grid(size_t need, size_t cap) {
     return 10 * g >= 9 * cap ? g : cap;
 }
 
+// The grid of the R = 1 kernel, apart from the device query so that the host side can plan range launches with it
+// (pem_persistent_grid).  Two regimes for the HBM-bound modes (profile written), measured interleaved on one box in the
+// streaming regime (tools/grid_mode_ab.py, tools/launch_size_probe.py --walk; profiles/grid_modes_r03.txt):
+//   * more than ONE_SHOT_ROUNDS rounds of work: a ONE-SHOT grid, one tile per wave, every workgroup handed to whichever CU has
+//     room.  With the static walk (tile me, me + nwaves, ...) the launch ends when the slowest wave has done its share while
+//     the others idle -- a tile's duration depends on where its wave sits; the dispatcher deals tiles out as slots free up
+//     instead: 206-208 against 214-219 us for the 1.25e6-sample shard (9.5 rounds), 213-215 against 222-226 for half of it.
+//     (A tile counter drawn from with atomics inside a persistent loop cost 36 registers, one wave per SIMD, 265 us; removed.)
+//   * fewer rounds: the persistent loop with balanced rounds -- the next tile's inputs are in flight while a tile is worked on
+//     and the tables are loaded once per wave, which is worth more than the dealing when a wave sees two or three tiles
+//     (312 512 samples, 2.4 rounds: 214-217 against 224-225 us per 1.25e6).
+constexpr long long ONE_SHOT_ROUNDS = 3;
+long long persistent_grid(long long ntiles, long long cus, long long per_cu, bool memory_bound) {
+    if (per_cu < 1) per_cu = 1;
+    long long g = cus * per_cu;
+    const long long need = (ntiles + WPB - 1) / WPB;
+    if (g > need) g = need;
+    if (!memory_bound) return g;
+    // (the modes bound by instruction issue want every slot: balanced, the reduced-QoI launch takes 45.3 instead of 44.4 us and
+    // the fused Monte-Carlo one 88 instead of 82 us; tools/grid_ab_probe.py)
+    static const bool one_shot = getenv("PEM_ONE_SHOT") ? atoi(getenv("PEM_ONE_SHOT")) != 0 : true;
+    if (one_shot && need > ONE_SHOT_ROUNDS * g) return need;
+    return (long long)balanced_grid((size_t)need, (size_t)g);
+}
+
 int fast_grid(long long per_cu, long long ntiles, bool memory_bound, unsigned* grid) {
-    static int cus[64] = {0};
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64) return fail(PEM_ERR_INVALID_ARG, "device index %d out of range", dev);
-    if (cus[dev] == 0) HIP_TRY(hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev));
+    int cus = 0;
+    HIP_TRY(pem::device_cus(&cus));
     if (const char* e = getenv("PEM_WAVES_PER_CU")) {          // tuning/experiments only
         const long long v = atoll(e) / WPB;
         if (v >= 1 && v < per_cu) per_cu = v;
     }
-    if (per_cu < 1) per_cu = 1;
-    long long g = (long long)cus[dev] * per_cu;
-    const long long need = (ntiles + WPB - 1) / WPB;
-    if (g > need) g = need;
-    // (the modes bound by instruction issue want every slot: balanced, the reduced-QoI launch takes 45.3 instead of 44.4 us and
-    // the fused Monte-Carlo one 88 instead of 82 us; tools/grid_ab_probe.py)
-    if (memory_bound) g = (long long)balanced_grid((size_t)need, (size_t)g);
-    *grid = (unsigned)g;
+    *grid = (unsigned)persistent_grid(ntiles, cus, per_cu, memory_bound);
+    if (const char* e = getenv("PEM_GRID_MULT")) {             // experiments: a grid of m x the resident slots (0 = one tile per wave)
+        const long long m = atoll(e), need = (ntiles + WPB - 1) / WPB, cap = (long long)cus * (per_cu < 1 ? 1 : per_cu);
+        *grid = (unsigned)((m <= 0 || m * cap > need) ? need : m * cap);
+    }
     return PEM_OK;
 }
 
-template <int L, bool COUPLED, int JMODE, bool MC = false>
-int launch_r1(const PlumeIO& io, const CoupledIO& cio, hipStream_t st, const McDesign& mc = McDesign{}) {
+template <int L, int JMODE, bool MC>
+size_t r1_lds_bytes(const PlumeIO& io) {
     size_t lds = (size_t)fast_lds_doubles<L, JMODE>() * 8;
     if (JMODE == 3) lds += (size_t)io.n_cond * (io.n_ang | 1) * 32;
     if (JMODE == 0) lds += (size_t)QPOLY_DOUBLES * 8;
     if (MC) lds += (size_t)MC_LDS_DOUBLES * 8;
-    const long long ntiles = (io.n + WAVE - 1) / WAVE;
-    unsigned grid = 0;
+    return lds;
+}
+
+// Workgroups resident per CU: bounded by the LDS (160 KB) and by the registers this instantiation was compiled to
+// (hipFuncGetAttributes; 512 per SIMD lane) -- the persistent loop must launch exactly as many as fit, a workgroup that
+// waits for a slot turns the tile split into a two-pass schedule -- and capped at two waves per SIMD, which measured
+// best for the HBM-bound modes, three for the profile-less ones: the fused Monte-Carlo kernel uses a third wave to
+// hide Philox's quarter-rate multiplies whenever its register count allows one (<= 168).
+template <int L, bool COUPLED, int JMODE, bool MC>
+int r1_per_cu(size_t lds, long long* per_cu) {
     auto kern = plume_r1_kernel<L, COUPLED, JMODE, MC>;
-    if (lds > 64 * 1024) {
-        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        HIP_TRY(attr);
-    }
-    // Workgroups resident per CU: bounded by the LDS (160 KB) and by the registers this instantiation was compiled to
-    // (hipFuncGetAttributes; 512 per SIMD lane) -- the persistent loop must launch exactly as many as fit, a workgroup that
-    // waits for a slot turns the tile split into a two-pass schedule -- and capped at two waves per SIMD, which measured
-    // best for the HBM-bound modes, three for the profile-less ones: the fused Monte-Carlo kernel uses a third wave to
-    // hide Philox's quarter-rate multiplies whenever its register count allows one (<= 168).
+    // the register count belongs to the code object (one architecture): once per process
+    static std::once_flag once;
     static int by_regs = 0;
-    if (by_regs == 0) {
+    static hipError_t err = hipSuccess;
+    std::call_once(once, [&] {
         hipFuncAttributes fa;
-        HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern)));
+        err = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern));
+        if (err != hipSuccess) return;
         const int regs = fa.numRegs > 0 ? ((fa.numRegs + 7) & ~7) : 256;
         by_regs = (512 / regs) * 4 / WPB;
         if (getenv("PEM_DEBUG_OCCUPANCY"))
             fprintf(stderr, "pem: plume_r1_kernel<%d,%d,%d,%d>: %d registers -> %d workgroups per CU\n", L, (int)COUPLED, JMODE,
                     (int)MC, fa.numRegs, by_regs);
-    }
-    long long cached_per_cu = (long long)(160 * 1024 / lds);
+    });
+    HIP_TRY(err);
+    long long v = (long long)(160 * 1024 / lds);
     const int cap = (JMODE == 0 ? 12 : 8) / WPB;
-    if (cached_per_cu > by_regs) cached_per_cu = by_regs;
-    if (cached_per_cu > cap) cached_per_cu = cap;
-    if (int rc = fast_grid(cached_per_cu, ntiles, JMODE == 1 || JMODE == 2, &grid)) return rc;
+    if (v > by_regs) v = by_regs;
+    if (v > cap) v = cap;
+    *per_cu = v;
+    return PEM_OK;
+}
+
+template <int L, bool COUPLED, int JMODE, bool MC = false>
+int launch_r1(const PlumeIO& io, const CoupledIO& cio, hipStream_t st, const McDesign& mc = McDesign{}) {
+    const size_t lds = r1_lds_bytes<L, JMODE, MC>(io);
+    const long long ntiles = (io.n + WAVE - 1) / WAVE;
+    unsigned grid = 0;
+    auto kern = plume_r1_kernel<L, COUPLED, JMODE, MC>;
+    if (lds > 64 * 1024) {
+        static pem::LdsAttrOnce attr;
+        HIP_TRY(attr.ensure(reinterpret_cast<const void*>(kern)));
+    }
+    long long per_cu = 0;
+    if (int rc = r1_per_cu<L, COUPLED, JMODE, MC>(lds, &per_cu)) return rc;
+    if (int rc = fast_grid(per_cu, ntiles, JMODE == 1 || JMODE == 2, &grid)) return rc;
     if constexpr (MC) hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * WPB), lds, st, io, cio, ntiles, mc);
     else hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * WPB), lds, st, io, cio, ntiles, NoDesign{});
     HIP_TRY(hipGetLastError());
@@ -1343,7 +1386,7 @@ int launch_r1(const PlumeIO& io, const CoupledIO& cio, hipStream_t st, const McD
 
 template <bool COUPLED, int JMODE>
 int dispatch_lanes(const PlumeIO& io, const CoupledIO& cio, hipStream_t st) {
-    switch (g_lanes) {
+    switch (g_lanes.load(std::memory_order_relaxed)) {
         case 2: return launch_r1<2, COUPLED, JMODE>(io, cio, st);
         case 8: return launch_r1<8, COUPLED, JMODE>(io, cio, st);
         default: return launch_r1<4, COUPLED, JMODE>(io, cio, st);
@@ -1356,17 +1399,16 @@ int launch_rfew(size_t n, hipStream_t st, const PlumeIO& io, const RadiiSmallArg
     constexpr size_t lds = (size_t)(TABLE_DOUBLES + NW * rfew_wave_doubles<R>()) * 8;
     static_assert(lds <= 160 * 1024, "the few-radii kernel's workgroup must fit the LDS");
     if (lds > 64 * 1024) {
-        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(plume_rfew_kernel<R>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        HIP_TRY(attr);
+        static pem::LdsAttrOnce attr;
+        HIP_TRY(attr.ensure(reinterpret_cast<const void*>(plume_rfew_kernel<R>)));
     }
-    int dev = 0, cus = 256;
-    HIP_TRY(hipGetDevice(&dev));
-    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    int cus = 256;
+    HIP_TRY(pem::device_cus(&cus));
     const size_t per_cu = (160 * 1024) / lds < 2 ? 1 : 2;          // persistent: workgroups resident per CU
     size_t grid = ((n + WAVE - 1) / WAVE + NW - 1) / NW;
     grid = balanced_grid(grid, (size_t)cus * per_cu);
     hipLaunchKernelGGL(plume_rfew_kernel<R>, dim3((unsigned)grid), dim3(WAVE * NW), lds, st, io, ra);
+    HIP_TRY(hipGetLastError());
     return PEM_OK;
 }
 
@@ -1529,6 +1571,45 @@ int pem_set_lanes_per_sample(int lanes) {
     return g_lanes;
 }
 
+int pem_persistent_grid(size_t n, int cus, int wg_per_cu, int memory_bound, size_t* workgroups, size_t* samples_per_round) {
+    if (!workgroups || !samples_per_round) return fail(PEM_ERR_INVALID_ARG, "pem_persistent_grid: NULL result pointer");
+    if (cus < 1 || wg_per_cu < 1) return fail(PEM_ERR_INVALID_ARG, "pem_persistent_grid: cus and wg_per_cu must be positive");
+    const long long ntiles = (long long)((n + WAVE - 1) / WAVE);
+    const long long g = persistent_grid(ntiles, cus, wg_per_cu, memory_bound != 0);
+    const long long resident = g < (long long)cus * wg_per_cu ? g : (long long)cus * wg_per_cu;   // a one-shot grid is longer than that
+    *workgroups = (size_t)g;
+    *samples_per_round = (size_t)resident * WPB * WAVE;
+    return PEM_OK;
+}
+
+int pem_coupled_occupancy(int profile_mode, int* cus, int* wg_per_cu) {
+    if (!cus || !wg_per_cu) return fail(PEM_ERR_INVALID_ARG, "pem_coupled_occupancy: NULL result pointer");
+    if (int rc = check_device()) return rc;
+    HIP_TRY(pem::device_cus(cus));
+    PlumeIO io{};
+    long long v = 0;
+    int rc;
+    // the instantiations pem_coupled_f64_dev / pem_coupled_mixed_dev launch at the current lanes-per-sample setting
+#define PEM_OCC(L_)                                                                                      \
+    (profile_mode == 0   ? r1_per_cu<L_, true, 0, false>(r1_lds_bytes<L_, 0, false>(io), &v)               \
+     : profile_mode == 1 ? r1_per_cu<L_, true, 1, false>(r1_lds_bytes<L_, 1, false>(io), &v)               \
+                         : r1_per_cu<L_, true, 2, false>(r1_lds_bytes<L_, 2, false>(io), &v))
+    if (profile_mode < 0 || profile_mode > 2) return fail(PEM_ERR_INVALID_ARG, "pem_coupled_occupancy: profile_mode must be 0, 1 or 2");
+    switch (g_lanes.load(std::memory_order_relaxed)) {
+        case 2: rc = PEM_OCC(2); break;
+        case 8: rc = PEM_OCC(8); break;
+        default: rc = PEM_OCC(4); break;
+    }
+#undef PEM_OCC
+    if (rc) return rc;
+    if (const char* e = getenv("PEM_WAVES_PER_CU")) {          // as fast_grid
+        const long long w = atoll(e) / WPB;
+        if (w >= 1 && w < v) v = w;
+    }
+    *wg_per_cu = (int)v;
+    return PEM_OK;
+}
+
 const double* pem_angle_grid(void) {
     std::call_once(g_grid_once, [] {
         // np.linspace(0, pi/2, 91): k * ((pi/2) / 90), last point exactly pi/2 (plume.py:53)
@@ -1646,6 +1727,22 @@ int pem_coupled_f64_dev(size_t n, double torr2pa, double radius, const double* P
     hipStream_t st = static_cast<hipStream_t>(stream);
     PlumeIO io{(long long)n, torr2pa, radius, P_b, c0, c1, c2, c3, c4, c5, sigma_cex, nullptr, nullptr, j_ion, div_angle, T_c, invalid};
     CoupledIO cio{V_a, T_e, V_vac, Pstar, P_T, mdot_a, a_1, V_cc, I_B0, T};
+    return j_ion ? dispatch_lanes<true, 1>(io, cio, st) : dispatch_lanes<true, 0>(io, cio, st);
+}
+
+// ---- coupled, inputs tile-interleaved: [ceil(n / 64)][15][64], one contiguous 7.5 KB block per 64-sample tile ----
+int pem_coupled_tiled_f64_dev(size_t n, double torr2pa, double radius, const double* x_tiled, double* V_cc, double* I_B0,
+                              double* T, double* j_ion, double* div_angle, double* T_c, uint8_t* invalid, pem_stream_t stream) {
+    if (n == 0) return PEM_OK;
+    if (!x_tiled || !V_cc || !div_angle || !T_c) return fail(PEM_ERR_INVALID_ARG, "pem_coupled_tiled: NULL array");
+    if (j_ion && !aligned16(j_ion)) return fail(PEM_ERR_INVALID_ARG, "pem_coupled_tiled: j_ion must be 16-byte aligned");
+    if (int rc = check_device()) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const double* x = x_tiled;   // rows in the order of pem_coupled_f64_dev's arguments: P_b V_a T_e V_vac Pstar P_T mdot_a a_1 c0..c5 sigma_cex
+    PlumeIO io{(long long)n, torr2pa, radius, x, x + 8 * WAVE, x + 9 * WAVE, x + 10 * WAVE, x + 11 * WAVE, x + 12 * WAVE, x + 13 * WAVE,
+               x + 14 * WAVE, nullptr, nullptr, j_ion, div_angle, T_c, invalid};
+    io.in_tile_stride = 15 * WAVE;
+    CoupledIO cio{x + 1 * WAVE, x + 2 * WAVE, x + 3 * WAVE, x + 4 * WAVE, x + 5 * WAVE, x + 6 * WAVE, x + 7 * WAVE, V_cc, I_B0, T};
     return j_ion ? dispatch_lanes<true, 1>(io, cio, st) : dispatch_lanes<true, 0>(io, cio, st);
 }
 

@@ -254,9 +254,8 @@ extern "C" int pem_jion_loglik_f64_dev(size_t n, int n_cond, int n_ang, const in
     size_t blocks = ((n + 15) / 16 + WAVES - 1) / WAVES;
     if (blocks > 256 * 2) blocks = 256 * 2;            // persistent: >= 47 KB of LDS per workgroup
     const size_t lds = (size_t)WAVES * (TILE + 2) * 8 + (size_t)n_cond * n_ang * 28 + 16;
-    static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(jion_loglik_kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    HIP_TRY(attr);
+    static pem::LdsAttrOnce attr;
+    HIP_TRY(attr.ensure(reinterpret_cast<const void*>(jion_loglik_kernel)));
     hipLaunchKernelGGL(jion_loglik_kernel, dim3((unsigned)blocks), dim3(BLOCK), lds, static_cast<hipStream_t>(stream),
                        (long long)n, n_cond, n_ang, kidx, weight, y, inv_std, j_ion, loglik);
     HIP_TRY(hipGetLastError());

@@ -56,11 +56,15 @@ __device__ __forceinline__ uint64_t feistel_permute(uint64_t i, uint64_t n, int 
 // (or every dimension if swap_dim == -2) is drawn from stream+1 instead of stream; -1 = plain.
 __global__ __launch_bounds__(256) void sample_kernel(long long n, uint64_t first, uint64_t seed, uint32_t stream,
                                                      int ndim, DimTable tab, int mode, uint64_t n_total, int half_bits,
-                                                     int swap_dim, double* __restrict__ out, size_t ld) {
+                                                     int swap_dim, double* __restrict__ out, size_t ld, int tiled) {
     const long long stride = (long long)gridDim.x * blockDim.x;
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const uint64_t g = first + (uint64_t)i;
+        // SoA: out[d][i] with leading dimension ld.  Tile-interleaved (pem_sample_tiled_f64_dev): [i / 64][d][i % 64], the
+        // layout pem_coupled_tiled_f64_dev reads -- one contiguous ndim x 512-byte block per 64-sample tile.
+        double* row = tiled ? out + (size_t)(i >> 6) * ((size_t)ndim * 64) + (size_t)(i & 63) : out + i;
+        const size_t dstride = tiled ? 64 : ld;
         for (int d0 = 0; d0 < ndim; d0 += 2) {
             // one Philox call serves both dimensions of the pair unless a Saltelli block draws them from different
             // streams (a wave-uniform choice)
@@ -75,17 +79,17 @@ __global__ __launch_bounds__(256) void sample_kernel(long long n, uint64_t first
                 if (d0 + 1 < ndim)
                     u[1] = ((double)feistel_permute(g, n_total, half_bits, k0, k1 ^ st1, (uint32_t)(d0 + 1)) + u[1]) / (double)n_total;
             }
-            out[(size_t)d0 * ld + i] = transform_call(tab.kind[d0], tab.a[d0], tab.b[d0], u[0]);
-            if (d0 + 1 < ndim) out[(size_t)(d0 + 1) * ld + i] = transform_call(tab.kind[d0 + 1], tab.a[d0 + 1], tab.b[d0 + 1], u[1]);
+            row[(size_t)d0 * dstride] = transform_call(tab.kind[d0], tab.a[d0], tab.b[d0], u[0]);
+            if (d0 + 1 < ndim) row[(size_t)(d0 + 1) * dstride] = transform_call(tab.kind[d0 + 1], tab.a[d0 + 1], tab.b[d0 + 1], u[1]);
         }
     }
 }
 
 int launch(size_t n, uint64_t first, uint64_t seed, uint32_t stream, int ndim, const int32_t* kind, const double* a,
-           const double* b, int mode, uint64_t n_total, int swap_dim, double* out, size_t ld, hipStream_t st) {
+           const double* b, int mode, uint64_t n_total, int swap_dim, double* out, size_t ld, hipStream_t st, int tiled = 0) {
     if (ndim < 1 || ndim > MAXDIM) return pem::fail(PEM_ERR_INVALID_ARG, "pem_sample: ndim must be in [1, %d]", MAXDIM);
     if (!kind || !a || !b || !out) return pem::fail(PEM_ERR_INVALID_ARG, "pem_sample: NULL array");
-    if (ld < n) return pem::fail(PEM_ERR_INVALID_ARG, "pem_sample: leading dimension smaller than n");
+    if (!tiled && ld < n) return pem::fail(PEM_ERR_INVALID_ARG, "pem_sample: leading dimension smaller than n");
     if (swap_dim < -2 || swap_dim >= ndim) return pem::fail(PEM_ERR_INVALID_ARG, "pem_sample: swap_dim out of range");
     if (n == 0) return PEM_OK;
     if (int rc = pem::check_device()) return rc;
@@ -105,7 +109,7 @@ int launch(size_t n, uint64_t first, uint64_t seed, uint32_t stream, int ndim, c
     size_t blocks = (n + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(sample_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (long long)n, first, seed, stream, ndim, tab,
-                       mode, n_total, half_bits, swap_dim, out, ld);
+                       mode, n_total, half_bits, swap_dim, out, ld, tiled);
     HIP_TRY(hipGetLastError());
     return PEM_OK;
 }
@@ -113,6 +117,11 @@ int launch(size_t n, uint64_t first, uint64_t seed, uint32_t stream, int ndim, c
 }  // namespace
 
 extern "C" {
+
+int pem_sample_tiled_f64_dev(size_t n, uint64_t first_index, uint64_t seed, uint32_t stream_id, int ndim, const int32_t* kind,
+                             const double* a, const double* b, int swap_dim, double* out, pem_stream_t stream) {
+    return launch(n, first_index, seed, stream_id, ndim, kind, a, b, 0, 0, swap_dim, out, 0, static_cast<hipStream_t>(stream), 1);
+}
 
 int pem_sample_f64_dev(size_t n, uint64_t first_index, uint64_t seed, uint32_t stream_id, int ndim, const int32_t* kind,
                        const double* a, const double* b, int swap_dim, double* out, size_t ld, pem_stream_t stream) {

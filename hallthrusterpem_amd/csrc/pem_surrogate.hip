@@ -204,9 +204,8 @@ void launch_predict(size_t n, int n_dim, int n_beta, const int32_t* index, const
     if (blocks > 256 * 8) blocks = 256 * 8;
     const size_t lds = (size_t)(2 * MAXM + n_dim) * BLOCK * sizeof(double);    // <= 100 KB at PEM_SURR_MAX_DIM
     if (lds > 64 * 1024) {
-        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(sparse_predict_kernel<NOUT, EXACT>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)attr;      // a refusal shows as a launch error below
+        static pem::LdsAttrOnce attr;
+        (void)attr.ensure(reinterpret_cast<const void*>(sparse_predict_kernel<NOUT, EXACT>));      // a refusal shows as a launch error below
     }
     hipLaunchKernelGGL((sparse_predict_kernel<NOUT, EXACT>), dim3((unsigned)blocks), dim3(BLOCK), lds, st, (long long)n, n_dim, n_beta,
                        index, coef, values, n_out, t, ld, out, ld_out, per_grid);

@@ -446,17 +446,15 @@ int pem_svd_compress_f64_dev(size_t n, int dof, int rank, int norm, double norm_
     size_t blocks = balanced_blocks((tiles + WAVES - 1) / WAVES, 256 * 2);
 #define PEM_SVD_LAUNCH(ROWS_, UN_, RT_, MODE_)                                                                            \
     do {                                                                                                             \
-        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(svd_compress_kernel<ROWS_, UN_, RT_, MODE_>), \
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);        \
-        HIP_TRY(attr);                                                                                               \
+        static pem::LdsAttrOnce attr;                                                                                \
+        HIP_TRY(attr.ensure(reinterpret_cast<const void*>(svd_compress_kernel<ROWS_, UN_, RT_, MODE_>)));             \
         hipLaunchKernelGGL((svd_compress_kernel<ROWS_, UN_, RT_, MODE_>), dim3((unsigned)blocks), dim3(BLOCK), lds, \
                            static_cast<hipStream_t>(stream), (long long)n, dof, rank, norm_scale, field, basis, latent); \
     } while (0)
 #define PEM_SVD_LAUNCH_MFMA()                                                                                          \
     do {                                                                                                             \
-        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(svd_compress_kernel<16, 12, 16, PEM_NORM_LOG10, true>), \
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);        \
-        HIP_TRY(attr);                                                                                               \
+        static pem::LdsAttrOnce attr;                                                                                \
+        HIP_TRY(attr.ensure(reinterpret_cast<const void*>(svd_compress_kernel<16, 12, 16, PEM_NORM_LOG10, true>)));   \
         hipLaunchKernelGGL((svd_compress_kernel<16, 12, 16, PEM_NORM_LOG10, true>), dim3((unsigned)blocks), dim3(BLOCK), lds, \
                            static_cast<hipStream_t>(stream), (long long)n, dof, rank, norm_scale, field, basis, latent); \
     } while (0)
@@ -514,9 +512,8 @@ int pem_svd_reconstruct_f64_dev(size_t n, int dof, int rank, int norm, double no
     const unsigned rgrid = grid_for(n, rbreg ? 3 : 2);       // persistent: workgroups per CU that the LDS admits
 #define PEM_SVD_RLAUNCH2(MODE_, BREG_)                                                                               \
     do {                                                                                                             \
-        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(svd_reconstruct_kernel<MODE_, BREG_>), \
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);        \
-        HIP_TRY(attr);                                                                                               \
+        static pem::LdsAttrOnce attr;                                                                                \
+        HIP_TRY(attr.ensure(reinterpret_cast<const void*>(svd_reconstruct_kernel<MODE_, BREG_>)));                    \
         hipLaunchKernelGGL((svd_reconstruct_kernel<MODE_, BREG_>), dim3(rgrid), dim3(BLOCK), lds,                    \
                            static_cast<hipStream_t>(stream), (long long)n, dof, rank, norm_scale, latent, basis, field); \
     } while (0)

@@ -45,16 +45,42 @@ def all_gather_rows(local, n_total: int, group=None):
     return out
 
 
-def chunk_bounds(n: int, chunks: int, align: int = 64):
+def chunk_bounds(n: int, chunks: int, align: int = 64, round_samples: int | None = None):
     """Cut one rank's shard of `n` samples into at most `chunks` contiguous pieces whose starts are multiples of `align`
-    (whole 64-sample kernel tiles; 16-byte aligned profile rows).  Returns [(first, count), ...]; pieces differ by at
-    most `align` samples and none is empty."""
+    (whole 64-sample kernel tiles; 16-byte aligned profile rows).  Returns [(first, count), ...]; none is empty.
+
+    `round_samples`: the samples ONE round of the persistent evaluation kernel covers (`launch_rounds`; resident waves x 64).
+    A range launch costs whole rounds -- a tile's duration is latency, so a round that is 38 % full takes as long as a full
+    one (tools/tail_probe.py) -- so with it every piece but the last is a whole number of rounds and the shard's own ragged
+    tail is the only partly filled round of the step, exactly as in the single launch.  The rounds are dealt out as evenly
+    as they divide, the longer pieces first (the last piece, which also carries the tail, is never the longest).  Without
+    it the pieces differ by at most `align` samples (the cut used when nothing is known about the kernel: CPU rehearsals)."""
     if n <= 0:
         return []
+    if round_samples:
+        if round_samples % align:
+            raise ValueError(f'a round of {round_samples} samples is not a multiple of the {align}-sample alignment')
+        rounds = (n + round_samples - 1) // round_samples
+        chunks = max(1, min(int(chunks), rounds))
+        per, extra = divmod(rounds, chunks)
+        edges, r = [0], 0
+        for k in range(chunks):
+            r += per + (1 if k < extra else 0)
+            edges.append(min(n, r * round_samples))
+        return [(a, b - a) for a, b in zip(edges, edges[1:]) if b > a]
     chunks = max(1, min(int(chunks), (n + align - 1) // align))
     tiles = (n + align - 1) // align
     edges = [min(n, ((k * tiles) // chunks) * align) for k in range(chunks)] + [n]
     return [(a, b - a) for a, b in zip(edges, edges[1:]) if b > a]
+
+
+def launch_rounds(n: int, cus: int, wg_per_cu: int, memory_bound: bool = True):
+    """(samples per round, rounds) of the persistent coupled kernel's launch over `n` samples on a device with `cus`
+    compute units holding `wg_per_cu` workgroups each: the library's own grid arithmetic (`pem_persistent_grid`, no GPU
+    needed) -- for a memory-bound mode the smallest grid that needs no more rounds than the full one (balanced rounds)."""
+    from . import _lib
+    _, per_round = _lib.persistent_grid(n, cus, wg_per_cu, memory_bound)
+    return per_round, (n + per_round - 1) // per_round
 
 
 class ChunkedGather:
@@ -70,7 +96,8 @@ class ChunkedGather:
     evaluate(first, count, out_rows): enqueue the model for local samples first .. first+count-1, writing the gathered
     QoIs (e.g. V_cc, div_angle, T_c) to out_rows[i][:count].  Nothing here knows what the model is."""
 
-    def __init__(self, n_local: int, rows: int, chunks: int, device, dtype=None, group=None, gather: bool = True):
+    def __init__(self, n_local: int, rows: int, chunks: int, device, dtype=None, group=None, gather: bool = True,
+                 round_samples: int | None = None):
         import torch
         import torch.distributed as dist
         self.group = group
@@ -78,7 +105,7 @@ class ChunkedGather:
         self.rank = dist.get_rank(group) if (gather and dist.is_initialized()) else 0
         self.gather = bool(gather) and dist.is_initialized()
         self.n_local, self.rows = int(n_local), int(rows)
-        self.bounds = chunk_bounds(self.n_local, chunks)
+        self.bounds = chunk_bounds(self.n_local, chunks, round_samples=round_samples)
         self.width = max((c for _, c in self.bounds), default=0)
         dtype = torch.float64 if dtype is None else dtype
         k = len(self.bounds)
@@ -86,16 +113,28 @@ class ChunkedGather:
         # concatenation layout (world * rows) per chunk: accepted by both the RCCL and the gloo backends
         self.recv = torch.zeros((k, self.world * self.rows, self.width), dtype=dtype, device=device) if self.gather else None
         self.pending = [None] * k
+        self._launches = 0
 
-    def step(self, evaluate):
+    def step(self, evaluate, streams=None):
+        """`streams`: optional list of torch streams the chunks are dealt onto in turn (continuing from step to step).  On
+        two streams chunk k+1's first waves take the slots chunk k's last round leaves free instead of waiting for the
+        launch to end; each chunk's collective is ordered after its own kernel (it is issued under that chunk's stream)."""
+        import contextlib
+        import torch
         import torch.distributed as dist
         for k, (first, count) in enumerate(self.bounds):
-            if self.pending[k] is not None:
-                self.pending[k].wait()          # stream-level: the previous gather of this chunk has read its buffer
-                self.pending[k] = None
-            evaluate(first, count, self.send[k])
-            if self.gather:
-                self.pending[k] = dist.all_gather_into_tensor(self.recv[k], self.send[k], group=self.group, async_op=True)
+            if streams:
+                ctx = torch.cuda.stream(streams[self._launches % len(streams)])
+                self._launches += 1
+            else:
+                ctx = contextlib.nullcontext()
+            with ctx:
+                if self.pending[k] is not None:
+                    self.pending[k].wait()      # stream-level: the previous gather of this chunk has read its buffer
+                    self.pending[k] = None
+                evaluate(first, count, self.send[k])
+                if self.gather:
+                    self.pending[k] = dist.all_gather_into_tensor(self.recv[k], self.send[k], group=self.group, async_op=True)
 
     def drain(self):
         for k, w in enumerate(self.pending):

@@ -96,6 +96,21 @@ class Design:
         _lib.check(rc)
         return out
 
+    def fill_tiled(self, out, n: int, first_index: int = 0, swap_dim: int = -1, stream=None):
+        """The numbers of `fill(method='mc')` written tile-interleaved: `out` is a [ceil(n / 64)][ndim][64] float64 CUDA
+        tensor (`CoupledBatch(layout='tile').inputs`), sample i at out[i // 64, :, i % 64]."""
+        import torch
+        assert out.is_cuda and out.dtype == torch.float64 and out.is_contiguous()
+        assert out.dim() == 3 and out.shape[1] == self.ndim and out.shape[2] == 64 and out.shape[0] * 64 >= n
+        s = torch.cuda.current_stream(out.device) if stream is None else stream
+        ptr = lambda arr: C.c_void_p(arr.ctypes.data)                                           # noqa: E731
+        with torch.cuda.device(out.device):
+            rc = _lib.load().pem_sample_tiled_f64_dev(int(n), first_index, self.seed, self.stream, self.ndim, ptr(self.kind),
+                                                      ptr(self.a), ptr(self.b), swap_dim, C.c_void_p(out.data_ptr()),
+                                                      C.c_void_p(s.cuda_stream))
+        _lib.check(rc)
+        return out
+
     def sample(self, n: int, device=None, **kw):
         import torch
         dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)

@@ -66,6 +66,18 @@ int pem_synchronize(pem_stream_t stream);   /* hipStreamSynchronize             
 int pem_set_lanes_per_sample(int lanes);
 /* The 91-point angle grid (host memory, valid for the life of the library): j_ion_coords.    */
 const double* pem_angle_grid(void);
+/* Launch geometry of the persistent coupled kernel, for callers that cut one GPU's shard into range launches (the
+ * multi-GPU pipeline of SURVEY.md section 8e; the reference's only parallel call site is the executor.map of
+ * scripts/gen_data.py:448-460, which has no notion of a launch).  A persistent wave walks 64-sample tiles
+ * w, w + waves, ...: a range that is a whole number of `samples_per_round` leaves no wave slot idle in its last round.
+ * pem_persistent_grid is pure arithmetic (no device needed): the workgroups a launch over n samples takes on a device
+ * with `cus` compute units holding `wg_per_cu` workgroups each (memory_bound, the profile-writing modes: balanced rounds
+ * up to three rounds of work, beyond that a one-shot grid of one tile per wave that the dispatcher deals out) and the
+ * samples the workgroups resident at one time cover.  pem_coupled_occupancy reports `cus` and `wg_per_cu` of
+ * pem_coupled_f64_dev (profile_mode 1), pem_coupled_mixed_dev (2) or the reduced-QoI launch (0, j_ion == NULL) on the
+ * calling thread's current device.                                                                                    */
+int pem_persistent_grid(size_t n, int cus, int wg_per_cu, int memory_bound, size_t* workgroups, size_t* samples_per_round);
+int pem_coupled_occupancy(int profile_mode, int* cus, int* wg_per_cu);
 
 /* ---- cathode_coupling  (cathode.py:16-38) --------------------------------------------------- */
 int pem_cathode_f64_dev(size_t n, const double* P_b, const double* V_a, const double* T_e,
@@ -129,6 +141,15 @@ int pem_coupled_f64(size_t n, double torr2pa, double radius, const double* P_b, 
                     const double* sigma_cex, double* V_cc, double* I_B0, double* T, double* j_ion,
                     double* div_angle, double* T_c, uint8_t* invalid);
 
+/* The same evaluation with the 15 inputs TILE-INTERLEAVED: x_tiled is [ceil(n / 64)][15][64] doubles -- for every 64-sample
+ * tile of the kernel the 15 rows (order of pem_coupled_f64_dev's arguments: P_b V_a T_e V_vac Pstar P_T mdot_a a_1 c0..c5
+ * sigma_cex) sit in one contiguous 7680-byte block, so a wave reads ONE block per tile instead of 512 bytes from each of 15
+ * arrays.  A second layout of the same `dict of arrays` the reference's callables take (cathode.py:26-31, plume.py:40-49);
+ * pem_sample_tiled_f64_dev writes it directly.  Results are bit-identical to pem_coupled_f64_dev.  Device pointers only. */
+int pem_coupled_tiled_f64_dev(size_t n, double torr2pa, double radius, const double* x_tiled, double* V_cc, double* I_B0,
+                              double* T, double* j_ion, double* div_angle, double* T_c, uint8_t* invalid,
+                              pem_stream_t stream);
+
 /* Mixed precision (BASELINE.json configs[4], "fp64 -> fp32 mixed with tolerance check"): identical fp64
  * arithmetic; only the 91-point profile is rounded once to fp32 when it is stored (j_ion_f32: [n][91]
  * floats, 16-byte aligned).  508 instead of 872 algorithmic bytes per evaluation.  Device pointers only.  */
@@ -162,6 +183,11 @@ int pem_sample_f64_dev(size_t n, uint64_t first_index, uint64_t seed, uint32_t s
 int pem_sample_lhs_f64_dev(size_t n, uint64_t first_index, uint64_t n_total, uint64_t seed, uint32_t stream_id,
                            int ndim, const int32_t* kind, const double* a, const double* b, double* out,
                            size_t ld, pem_stream_t stream);
+/* pem_sample_f64_dev's numbers in the tile-interleaved layout of pem_coupled_tiled_f64_dev: out is
+ * [ceil(n / 64)][ndim][64] (sample i of the call at out[(i / 64) * ndim * 64 + d * 64 + i % 64]).             */
+int pem_sample_tiled_f64_dev(size_t n, uint64_t first_index, uint64_t seed, uint32_t stream_id, int ndim,
+                             const int32_t* kind, const double* a, const double* b, int swap_dim, double* out,
+                             pem_stream_t stream);
 
 /* Saltelli accumulation for the Sobol' estimators (uq.sobol_sa at scripts/pem_v0/sobol.py:113 -- uqtils, third-party,
  * parity UNPINNED; estimators stated in hallthrusterpem_amd/drivers.py).  fA / fB / fAB: [nq][ld] QoI rows of the

@@ -41,6 +41,21 @@ def test_single_gpu_line():
     assert line['config']['batches_rotated'] == 8 and sb['value'] > 0 and 'NOT the headline' in sb['note']
     if r['traffic'] is not None:
         assert 'not measured in this run' in r['traffic_source']
+    # launches are dealt onto two streams by default; the one-stream rate of the same steps and the geometry of the launch
+    # are carried beside, and the roofline object keeps the duration of isolated launches
+    c = line['config']
+    assert c['streams'] == 2 and c['single_stream']['value'] > 0 and c['input_layout'] == 'tile'
+    assert r['steps_overlapped']['streams'] == 2 and abs(r['steps_overlapped']['ms_per_step'] - line['ms_per_step']) < 1e-12
+    assert c['launch_rounds']['chunks'] == [[0, 131072]] and c['launch_rounds']['samples_per_round'] > 0
+
+
+def test_single_stream_and_soa_inputs_are_options():
+    out = subprocess.run([sys.executable, str(ROOT / 'bench.py'), *SMALL, '--no-cpu-baseline', '--streams', '1', '--layout', 'soa'],
+                         capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = _one_json_line(out.stdout)
+    assert line['config']['streams'] == 1 and line['config']['single_stream'] is None and line['roofline']['steps_overlapped'] is None
+    assert line['config']['input_layout'] == 'soa' and line['value'] > 0
 
 
 def test_single_gpu_line_carries_the_whole_config():
@@ -53,7 +68,15 @@ def test_single_gpu_line_carries_the_whole_config():
     fc = line['config']['full_config']
     assert fc['samples'] == 2_000_000 and fc['bytes_per_launch'] == 872 * 2_000_000 and fc['value'] > 1e9
     assert abs(fc['frac_of_peak'] - fc['achieved_GBs'] / 8000.0) < 1e-12 and 0.3 < fc['frac_of_peak'] < 1.0
-    assert line['config']['samples_per_gpu'] == 1_250_000 and line['roofline']['traffic_source'].startswith('replayed from profiles/')
+    # roofline.traffic is replayed from a committed counter measurement only while that measurement was taken on the kernel
+    # sources in the tree (kernel_srchash); after a kernel edit it is dropped, not quoted
+    src = line['roofline']['traffic_source']
+    assert line['config']['samples_per_gpu'] == 1_250_000
+    if line['roofline']['traffic'] is None:
+        assert src.startswith('none: ')
+    else:
+        assert src.startswith('replayed from profiles/') and 'kernel_srchash' in src
+        assert 0.9 * 872 * 1_250_000 < line['roofline']['traffic'] < 1.3 * 872 * 1_250_000
     cb = line['cpu_baseline']
     assert cb['kind'] == 'port' and cb['reference_numpy']['value'] == 1.4e5 and cb['reference_numpy']['cores'] == 1
 

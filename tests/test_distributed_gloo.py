@@ -18,7 +18,8 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / 'tests'))
 
-from hallthrusterpem_amd.distributed import ChunkedGather, all_gather_rows, chunk_bounds, evaluate_sharded, max_shard, shard_bounds  # noqa: E402
+from hallthrusterpem_amd.distributed import (ChunkedGather, all_gather_rows, chunk_bounds, evaluate_sharded, launch_rounds,  # noqa: E402
+                                             max_shard, shard_bounds)
 
 
 def test_shard_bounds_tile_the_batch():
@@ -86,6 +87,38 @@ def test_chunk_bounds_tile_a_shard_on_tile_boundaries():
             assert all(x[0] + x[1] == y[0] for x, y in zip(b, b[1:])) and len(b) <= max(1, k)
             assert max(c for _, c in b) - min(c for _, c in b[:-1] or b) <= 64
     assert chunk_bounds(0, 4) == []
+
+
+@pytest.mark.parametrize('cus,wg_per_cu', [(256, 2), (256, 1), (304, 2), (64, 3)])
+def test_every_chunk_of_the_pipeline_is_a_whole_number_of_rounds(cus, wg_per_cu):
+    """The N > 1 schedule cuts a shard into range launches.  A persistent launch costs whole rounds of
+    its grid -- a partly filled round takes as long as a full one -- so every piece but the last must be a whole number of
+    the rounds the LIBRARY's grid arithmetic gives that very piece (pem_persistent_grid: no GPU needed), the last piece
+    carries the shard's own tail and nothing else, and the step as a whole needs exactly the rounds of the single launch
+    (round 2 cut on 64-sample boundaries: 4 x 3 rounds against 10 for the BASELINE shard)."""
+    from hallthrusterpem_amd import _lib
+    for n in (1_250_000, 1_250_001, 10_000_000, 131_072, 700_000, 65, 64 * 4 * cus * wg_per_cu * 3):
+        per_round, rounds = launch_rounds(n, cus, wg_per_cu)
+        assert per_round % 256 == 0 and (rounds - 1) * per_round < n <= rounds * per_round
+        for k in (1, 2, 3, 4, 8, 64):
+            b = chunk_bounds(n, k, round_samples=per_round)
+            assert b[0][0] == 0 and sum(c for _, c in b) == n and all(x[0] + x[1] == y[0] for x, y in zip(b, b[1:]))
+            assert len(b) == min(k, rounds) and all(first % 64 == 0 and c > 0 for first, c in b)
+            total_rounds = 0
+            for i, (first, count) in enumerate(b):
+                grid, spr = _lib.persistent_grid(count, cus, wg_per_cu)      # what the launch of this piece will take
+                r = -(-count // spr)
+                total_rounds += r
+                if i < len(b) - 1:
+                    assert spr == per_round and count == r * per_round, (n, k, i, count, spr, per_round)
+                else:                                                          # the tail piece carries the shard's ragged end
+                    assert (r - 1) * spr < count <= r * spr
+            assert total_rounds == rounds, (n, k, b)
+            sizes = [-(-c // per_round) for _, c in b]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+    # round 2's cut of the BASELINE shard, for the record: three rounds per piece, the last one 38 % full
+    old = chunk_bounds(1_250_000, 4)
+    assert sum(-(-c // 131_072) for _, c in old) == 12 and launch_rounds(1_250_000, 256, 2)[1] == 10
 
 
 def _pipeline_worker(rank, world, port, n_local, chunks, out_dir):

@@ -228,6 +228,71 @@ def test_device_tensors_match_host_path(pem):
     assert np.array_equal(b['T_c'].cpu().numpy(), a['T_c'], equal_nan=True)
 
 
+@pytest.mark.parametrize('n', [1, 63, 64, 65, 4096 + 37, 1_250_000])
+def test_tile_interleaved_inputs_are_the_same_evaluation(pem, oc, n):
+    """pem_coupled_tiled_f64_dev reads the 15 inputs from [tiles][15][64] blocks instead of 15 arrays: bit-identical to
+    pem_coupled_f64_dev (profile and reduced-QoI mode, whole batch and range launches), and held to the oracle itself."""
+    import torch
+    from hallthrusterpem_amd.batch import CoupledBatch
+    from hallthrusterpem_amd.models.coupled import COUPLED_INPUTS
+    oc.set_threads(16)
+    x = coupled_inputs(n, seed=31)
+    for profile in (True, False):
+        a = CoupledBatch(n, profile=profile, layout='soa')
+        b = CoupledBatch(n, profile=profile, layout='tile')
+        a.set_inputs(x)
+        b.set_inputs(x)
+        assert b.inputs.shape == ((n + 63) // 64, 15, 64)
+        assert torch.equal(b.inputs_soa(), a.inputs)
+        a.run()
+        b.run()
+        torch.cuda.synchronize()
+        oa, ob = a.outputs(), b.outputs()
+        for k in oa:
+            assert np.array_equal(oa[k].cpu().numpy(), ob[k].cpu().numpy(), equal_nan=True), (k, profile)
+        if n > 300:                    # range launches of the tiled batch: from a multiple of 64 on
+            c = CoupledBatch(n, profile=profile, layout='tile')
+            c.set_inputs(x)
+            cut = 128 * (n // 300)
+            c.run(first=0, count=cut)
+            c.run(first=cut)
+            torch.cuda.synchronize()
+            for k, v in c.outputs().items():
+                assert np.array_equal(v.cpu().numpy(), oa[k].cpu().numpy(), equal_nan=True), (k, 'range')
+            with pytest.raises(ValueError):
+                c.run(first=2, count=10)
+    want = oc.coupled(x, pem.constants.TORR_2_PA)
+    b = CoupledBatch(n, layout='tile')
+    b.load_soa(torch.stack([torch.from_numpy(np.ascontiguousarray(x[k])) for k in COUPLED_INPUTS]).cuda())
+    b.run()
+    torch.cuda.synchronize()
+    got = {k: v.cpu().numpy() for k, v in b.outputs().items()}
+    for k in ('V_cc', 'j_ion', 'T_c'):
+        assert rel_err(got[k], want[k]) <= RTOL, k
+    assert div_err(got['div_angle'], want['div_angle']) <= RTOL and np.array_equal(got['invalid'], want['invalid'])
+
+
+def test_mixed_profile_ranges_need_a_multiple_of_four(pem):
+    """364-byte fp32 profile rows: a range launch must start 16-byte aligned, i.e. at a multiple of 4 samples -- an even
+    `first` that is not one used to reach the library and come back as a generic INVALID_ARG."""
+    import torch
+    from hallthrusterpem_amd.batch import CoupledBatch
+    x = coupled_inputs(1000, seed=5)
+    whole = CoupledBatch(1000, mixed=True)
+    whole.set_inputs(x)
+    whole.run()
+    parts = CoupledBatch(1000, mixed=True)
+    parts.set_inputs(x)
+    with pytest.raises(ValueError, match='multiple of 4'):
+        parts.run(first=2, count=100)
+    with pytest.raises(ValueError, match='multiple of 2'):
+        CoupledBatch(1000).run(first=3, count=100)
+    parts.run(first=0, count=500)
+    parts.run(first=500)
+    torch.cuda.synchronize()
+    assert torch.equal(whole.j_ion, parts.j_ion) and torch.equal(whole.qoi, parts.qoi)
+
+
 # ---------------------------------------------------------------------------------------------- full-size properties
 def test_config2_full_size_properties(pem, oc):
     """BASELINE.json configs[1]: 1e6 MC samples of the plume model, R = 1, fp64.  (a) ALL 1e6 samples against the

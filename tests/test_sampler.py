@@ -70,6 +70,14 @@ def test_hip_sampler_matches_numpy_restatement():
     whole = d.sample(3000)
     parts = torch.cat([d.sample(1000), d.sample(2000, first_index=1000)], dim=1)
     assert torch.equal(whole, parts)
+    # the same numbers written tile-interleaved ([tiles][15][64], the layout of pem_coupled_tiled_f64_dev), ragged last tile
+    for m in (3000, 64, 1):
+        tiled = torch.zeros(((m + 63) // 64, d.ndim, 64), dtype=torch.float64, device='cuda')
+        d.fill_tiled(tiled, m, first_index=0)
+        assert torch.equal(tiled.permute(1, 0, 2).reshape(d.ndim, -1)[:, :m], whole[:, :m])
+    tiled = torch.zeros((8, d.ndim, 64), dtype=torch.float64, device='cuda')
+    d.fill_tiled(tiled, 500, swap_dim=8)
+    assert torch.equal(tiled.permute(1, 0, 2).reshape(d.ndim, -1)[:, :500], AB)
     # Latin hypercube
     L = d.sample(4097, method='lhs', n_total=4097).cpu().numpy()
     Lw = snp.sample(4097, 0, 2026, 3, d.kind, d.a, d.b, mode='lhs', n_total=4097)

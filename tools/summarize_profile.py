@@ -3,6 +3,7 @@
 profiles/traffic_<tag>.json (HBM bytes per launch of the coupled kernel, with the gfx950 FETCH_SIZE x2 correction of
 MI355X_MICROARCH.md section HBM).   Usage: python tools/summarize_profile.py <tag> [samples_per_launch]"""
 import csv
+import os
 import json
 import sys
 from collections import defaultdict
@@ -69,7 +70,10 @@ for k, v in sorted(counters.items()):
     mean[k] = sum(v) / len(v)
     lines.append(f'| {k} | {mean[k]:.6g} | {len(v)} |')
 lines.append('')
-rec = {'tag': tag, 'samples_per_launch': n_samples, 'kernel': KERNEL, 'kernel_mean_us': kern_mean_us}
+sys.path.insert(0, str(ROOT))
+from bench import kernel_source_hash     # noqa: E402  (the digest bench.py checks before it replays this record)
+rec = {'tag': tag, 'samples_per_launch': n_samples, 'kernel': KERNEL, 'kernel_mean_us': kern_mean_us,
+       'kernel_srchash': kernel_source_hash(), 'layout': os.environ.get('PEM_PROFILE_LAYOUT', 'soa')}
 if 'FETCH_SIZE' in mean and 'WRITE_SIZE' in mean:
     # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reads exactly half the bytes of a wide coalesced
     # stream (128-B requests tallied at 64 B) -> doubled; WRITE_SIZE is exact for 16-B/lane streaming stores.
