@@ -291,8 +291,12 @@ int launch(const char* who, size_t n_base, uint64_t first_index, uint64_t seed, 
     if (!kind || !a || !b || !varied || !partial || !flags) return pem::fail(PEM_ERR_INVALID_ARG, "%s: NULL array", who);
     if (n_varied < 1 || n_varied > NIN) return pem::fail(PEM_ERR_INVALID_ARG, "%s: 1 <= n_varied <= %d", who, NIN);
     if (n_blocks < 1) return pem::fail(PEM_ERR_INVALID_ARG, "%s: n_blocks must be positive", who);
-    if (n_base == 0) return PEM_OK;
     if (int rc = pem::check_device()) return rc;
+    if (n_base == 0) {   // an empty shard contributes zero to every sum: the caller adds the partials up whatever n_base was
+        HIP_TRY(hipMemsetAsync(partial, 0, (size_t)n_blocks * (2 + 2 * n_varied) * NQ * sizeof(double), static_cast<hipStream_t>(stream)));
+        HIP_TRY(hipMemsetAsync(flags, 0, (size_t)n_blocks * 2 * sizeof(uint64_t), static_cast<hipStream_t>(stream)));
+        return PEM_OK;
+    }
     SaltelliArg s{};
     s.seed = seed;
     s.first = first_index;

@@ -296,6 +296,7 @@ def main():
           **{f'nan30_{k}': v for k, v in nan_q3.items()}, **{f'out30_{k}': v for k, v in out_q3.items()})
 
     _hallthruster_jl_golden(thruster)
+    _pem_v0_variable_table()
 
     with open(OUT / 'thruster_host.json', 'w') as fd:
         json.dump({'fidelity': fid, 'convert_map': p2j, 'convert_to_julia': jd, 'convert_to_pem': back,
@@ -331,6 +332,45 @@ def fake_run_simulation(json_input, jl_env=None, jl_script=None, **kwargs):
         with open(target, 'w') as fd:
             json.dump(out, fd)
     return json.loads(json.dumps(out))
+
+
+def _pem_v0_variable_table():
+    """The PEM-v0 variable table as DATA: scripts/pem_v0/pem_v0_SPT-100.yml read with
+    constructors that ignore amisc's tags (`!System`, `!Component`, `!Variable`, `!!python/name:`), every variable of every
+    component with the fields the sampling loops use -- name, category, nominal, domain, distribution, norm, units,
+    compression -- exactly as the file spells them (strings stay strings: `U(1, 5)`, `(1.0e-8, 1.0e-4)`, `linear(1e6)`).
+    tests/test_variable_table.py parses them and holds sampling.PEM_V0_PRIORS, system.PemV0System and the synthetic inputs of
+    bench.py / tests/_inputs.py to the result."""
+    import yaml
+
+    class Loader(yaml.SafeLoader):
+        pass
+
+    def plain(loader, suffix, node):
+        if isinstance(node, yaml.MappingNode):
+            return loader.construct_mapping(node, deep=True)
+        if isinstance(node, yaml.SequenceNode):
+            return loader.construct_sequence(node, deep=True)
+        return suffix if node.value == '' else loader.construct_scalar(node)     # !!python/name:a.b.c -> 'a.b.c'
+    Loader.add_multi_constructor('!', plain)
+    Loader.add_multi_constructor('tag:yaml.org,2002:python/name:', plain)
+    yml = REF.parents[1] / 'scripts' / 'pem_v0' / 'pem_v0_SPT-100.yml'
+    with open(yml, 'r', encoding='utf-8') as fd:
+        system = yaml.load(fd, Loader=Loader)
+    keep = ('name', 'category', 'nominal', 'domain', 'distribution', 'norm', 'units', 'compression')
+    table = {'source': 'scripts/pem_v0/pem_v0_SPT-100.yml', 'system': system['name'], 'hallmd_version': system['hallmd_version'],
+             'components': []}
+    for comp in system['components']:
+        rec = {'name': comp['name'], 'model': comp['model'], 'vectorized': bool(comp.get('vectorized', False))}
+        for k in ('sweep_radius', 'model_fidelity', 'thruster'):
+            if k in comp:
+                rec[k] = comp[k]
+        for side in ('inputs', 'outputs'):
+            rec[side] = [{k: v[k] for k in keep if k in v} for v in comp[side]]
+        table['components'].append(rec)
+    with open(OUT / 'pem_v0_variables.json', 'w') as fd:
+        json.dump(table, fd, indent=1, sort_keys=True)
+    print('wrote pem_v0_variables.json')
 
 
 def _hallthruster_jl_golden(thruster):
@@ -393,8 +433,38 @@ def _hallthruster_jl_golden(thruster):
         (dev / 'thruster.yml').write_text(yaml.safe_dump(spec))
         loaded = load_thruster(dev)
         loaded_txt = json.dumps(loaded).replace(str(dev.resolve()), '<DEVICE>')
+    # ... and where the reference's walk is particular (src/hallmd/utils.py:67-85): a file name referenced twice (the first
+    # occurrence in depth-first key order is the only one replaced), a reference two levels deep (replaced), one three levels
+    # deep (the walk restarts from the top-level dict at every key: KeyError), names inside lists (never looked at)
+    more = []
+    layouts = {
+        'twice': {'name': 'D', 'magnetic_field': {'file': 'bfield.csv'}, 'backup': {'file': 'bfield.csv'}, 'plain': 'bfield.csv'},
+        'two_levels': {'name': 'D', 'a': {'b': 'fields/extra.csv'}, 'shielded': True},
+        'three_levels': {'name': 'D', 'a': {'b': {'c': 'bfield.csv'}}},
+        'three_levels_by_path': {'name': 'D', 'a': {'b': {'c': 'fields/extra.csv'}}},
+        'in_a_list': {'name': 'D', 'files': ['bfield.csv', 'fields/extra.csv'], 'magnetic_field': {'file': 'bfield.csv'}},
+        'bare_name_of_nested_file': {'name': 'D', 'other': {'table': 'extra.csv'}},
+        'top_level': {'name': 'D', 'file': 'bfield.csv'},
+        'json_spec': {'name': 'D', 'magnetic_field': {'file': 'bfield.csv'}},
+    }
+    for label, lay in layouts.items():
+        with tempfile.TemporaryDirectory() as tmp:
+            dev = Path(tmp) / 'Dev'
+            (dev / 'fields').mkdir(parents=True)
+            (dev / 'bfield.csv').write_text('z,B\n0,0.01\n')
+            (dev / 'fields' / 'extra.csv').write_text('x\n')
+            fname = 'thruster.json' if label == 'json_spec' else 'thruster.yml'
+            text = json.dumps(lay) if label == 'json_spec' else yaml.safe_dump(lay, sort_keys=False)
+            (dev / fname).write_text(text)
+            rec = {'label': label, 'spec_text': text, 'filename': fname}      # the text: key ORDER decides which mention is first
+            try:
+                got = load_thruster(dev, fname)
+                rec['loaded'] = json.loads(json.dumps(got).replace(str(dev.resolve()), '<DEVICE>'))
+            except Exception as e:                     # noqa: BLE001
+                rec['raises'] = type(e).__name__
+            more.append(rec)
     with open(OUT / 'hallthruster_jl.json', 'w') as fd:
-        json.dump({'cases': out, 'device_spec': spec, 'device_loaded': json.loads(loaded_txt)}, fd, indent=1, sort_keys=True)
+        json.dump({'cases': out, 'device_spec': spec, 'device_loaded': json.loads(loaded_txt), 'device_cases': more}, fd, indent=1, sort_keys=True)
     print('wrote hallthruster_jl.json')
 
 

@@ -65,6 +65,9 @@ def test_fused_saltelli_launch_equals_the_block_by_block_fp32_pipeline():
         pri[k] = sampling.Prior(sampling.UNIFORM, v, v, 'fixed')
     design = sampling.Design(priors=pri, seed=11)
     varied = [i for i, k in enumerate(design.names) if k not in fixed]
+    for precision in ('fp32', 'fp64'):      # an empty shard adds nothing (the partials used to be left uninitialised)
+        sums, flags = saltelli_sums(design, varied, 0, precision=precision)
+        assert float(sums.abs().sum()) == 0.0 and int(flags.sum()) == 0
     for N, first in ((20_000, 0), (1000, 12345), (63, 7)):
         sums, flags = saltelli_sums(design, varied, N, first_index=first)
         x64 = torch.empty((15, N), dtype=torch.float64, device='cuda')

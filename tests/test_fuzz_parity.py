@@ -10,14 +10,20 @@ The named seeds are the ones round-1 campaigns ended red on ("what's
   seed 867  three radii, beams of opposite sign: div_angle off by 5e-6 before the wave-per-sample kernel summed such
             samples angle by angle as the reference does;
   seed 940  three radii: j_ion 1.3e-9 relative where a negative j_cex cancels the beams;
-  seed 1100 coupled, full profile: j_ion 1.01e-10 relative, same cancellation."""
+  seed 1100 coupled, full profile: j_ion 1.01e-10 relative, same cancellation;
+  seed 269  five radii, a sample whose only non-zero beam is narrower than the 1-degree grid: cos_div = 1 - 2 eps in the
+            oracle and 1 on the device, both inside the 4 eps bound, i.e. div_angle = 3.0e-8 against 0.  Round 2's campaign
+            stopped here because the CHECKER mapped the angle difference back to the cosine as d^2 (it is d^2 / 2 at the
+            pole); `divergence_error` / `conftest.div_err` evaluate |cos a - cos b| exactly since.  The seed keeps the R = 5
+            path and the metric under the driver-run suite; `test_divergence_metric_at_the_pole` pins the metric itself."""
 import sys
 from pathlib import Path
 
+import numpy as np
 import pytest
 
 ROOT = Path(__file__).resolve().parents[1]
-NAMED_SEEDS = ['65', '867', '940', '1100']
+NAMED_SEEDS = ['65', '269', '867', '940', '1100']
 
 
 @pytest.mark.gpu
@@ -26,3 +32,35 @@ def test_wild_inputs_match_the_oracle(monkeypatch):
     import fuzz_parity
     monkeypatch.setattr(sys, 'argv', ['fuzz_parity.py', '--seeds', '60', '--seed-list', *NAMED_SEEDS, '--n', '20000'])
     fuzz_parity.main()
+
+
+def test_divergence_metric_at_the_pole():
+    """The two comparisons of div_angle = arccos(cos_div) (`conftest.div_err`, `parity_rules.divergence_error`) at the pole
+    cos_div -> 1, with the pair seed 269 produced: cos_div = 1 - 2 eps on one side, exactly 1 on the other.  The angles are
+    arccos(1 - 2 eps) = 3.0e-8 and 0 -- relative difference 1 -- while the cosines differ by 2 eps, inside every bound used
+    (4 eps for a quotient of two rounded sums): the pair must pass, and a pair whose cosines differ by more must not."""
+    import parity_rules as pr
+    from conftest import div_err
+    eps = pr.EPS                                        # 2^-52, the eps of parity_rules
+    a = np.arccos(np.array([1.0 - 2 * eps]))            # 2.98e-08
+    z = np.array([0.0])
+    assert 2.9e-8 < a[0] < 3.0e-8
+    # conftest.div_err: 8 ulp of cos_div by default
+    assert div_err(a, z) == 0.0 and div_err(z, a) == 0.0
+    # 2 eps is more than cos_ulps = 1 allows: the angle's own error is reported (relative; absolute where the wanted angle is 0)
+    assert div_err(z, a, cos_ulps=1) == 1.0 and div_err(a, z, cos_ulps=1) == a[0]
+    far = np.arccos(np.array([1.0 - 64 * eps]))
+    assert div_err(z, far) == 1.0 and div_err(far, z) == far[0] > 1e-7
+    # away from the pole the same 2 eps of the cosine is 1e-16 of the angle and passes as a relative error
+    mid = np.arccos(np.array([0.5])), np.arccos(np.array([0.5 - 2 * eps]))
+    assert 0.0 <= div_err(mid[0], mid[1]) < 1e-15
+    # parity_rules.divergence_error with the bound of a plain sample (cos_rel = 4 eps)
+    bounds = {'comparable': np.array([True]), 'cos_div': np.array([1.0]), 'cos_rel': np.array([4 * eps]), 'cond_cos': np.array([1.0])}
+    for got, want in ((a, z), (z, a)):
+        r = pr.divergence_error(got, want, None, None, bounds)
+        assert r['err_div'] == 0.0, r
+    r = pr.divergence_error(z, far, None, None, bounds)
+    assert r['err_div'] == 1.0                           # 64 eps of the cosine is outside the bound: the angle's own error is reported
+    # the mapping that stopped round 2's campaign, for the record: d^2 overstates the cosine difference at the pole by 2
+    d = float(a[0])
+    assert abs(2 * np.sin(0.5 * d) ** 2 - 2 * eps) < 1e-3 * eps and d * d > 3.9 * eps

@@ -173,3 +173,29 @@ def test_default_backend_batched_equals_thruster_analytic():
     assert np.isnan(out['T'][[3, 500]]).all() and np.isnan(out['u_ion'][3]).all() and np.isfinite(np.delete(out['T'], [3, 500])).all()
     out = hallthruster_jl({k: np.abs(v) for k, v in x.items()}, thruster=None, config=cfg, model_fidelity=(1, 0), shock_threshold=0.09)
     assert len(out['errors']) == n and out['errors'][0].startswith('Exception due to shock-like behavior')
+
+
+def test_load_thruster_follows_the_reference_walk(g, tmp_path):
+    """src/hallmd/utils.py:67-85 run on device descriptions where its walk is particular (tests/golden/make_golden.py
+    `device_cases`): a file mentioned twice (only the first mention, in depth-first key order, becomes absolute), a mention two
+    dicts deep, the bare name of a file in a sub-directory, names inside a list (never looked at), a .json description.  Three
+    dicts deep the reference ends in a KeyError (its walk restarts from the top-level dict at every key); that case is the
+    one documented deviation: the mention is replaced where it stands."""
+    import yaml
+    from hallthrusterpem_amd.utils import load_thruster
+    assert {c['label'] for c in g['device_cases']} >= {'twice', 'two_levels', 'three_levels', 'in_a_list', 'bare_name_of_nested_file'}
+    for case in g['device_cases']:
+        dev = tmp_path / case['label'] / 'Dev'
+        (dev / 'fields').mkdir(parents=True)
+        (dev / 'bfield.csv').write_text('z,B\n0,0.01\n')
+        (dev / 'fields' / 'extra.csv').write_text('x\n')
+        (dev / case['filename']).write_text(case['spec_text'])
+        got = json.loads(json.dumps(load_thruster(dev, case['filename'])).replace(str(dev.resolve()), '<DEVICE>'))
+        if 'raises' in case:
+            assert case['raises'] == 'KeyError' and case['label'].startswith('three_levels')
+            want = yaml.safe_load(case['spec_text'])
+            leaf = want['a']['b']
+            leaf['c'] = '<DEVICE>/' + ('fields/extra.csv' if leaf['c'].endswith('extra.csv') else 'bfield.csv')
+            assert got == want, case['label']
+        else:
+            assert got == case['loaded'], case['label']
