@@ -56,6 +56,14 @@ SIGNATURES = {
     'pem_key_minmax_f64_dev': (C.c_int, [_sz, C.c_int, _dp, _sz, _dp, _dp, _dp, _dp]),
     'pem_range_hist_f64_dev': (C.c_int, [_sz, C.c_int, _dp, _sz, C.c_int, _dp, _dp, C.c_int, _dp, _dp]),
     'pem_range_narrow_dev': (C.c_int, [C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp]),
+    'pem_qsel_bins': (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'pem_qsel_minmax_f64_dev': (C.c_int, [_sz, C.c_int, _dp, _sz, _dp, _dp, _dp, _dp]),
+    'pem_qsel_hist1_f64_dev': (C.c_int, [_sz, C.c_int, _dp, _sz, _dp, _dp, C.c_int, _dp, _dp]),
+    'pem_qsel_decide1_dev': (C.c_int, [C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp, _dp]),
+    'pem_qsel_hist2_f64_dev': (C.c_int, [_sz, C.c_int, _dp, _sz, _dp, _dp, C.c_int, _dp, C.c_int, C.c_int, _dp, _dp]),
+    'pem_qsel_decide2_dev': (C.c_int, [C.c_int, C.c_int, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
+    'pem_qsel_compact_f64_dev': (C.c_int, [_sz, C.c_int, _dp, _sz, _dp, _dp, C.c_int, _dp, _dp, _dp, C.c_int, C.c_int, C.c_uint32, _dp, _dp, _dp]),
+    'pem_qsel_select_dev': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_uint32, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     'pem_quantiles_f64_dev': (C.c_int, [_sz, C.c_int, _dp, _sz, C.c_int, _dp, _dp, _dp, _dp, _dp]),
     'pem_sobol_partial_f64_dev': (C.c_int, [_sz, C.c_int, _sz, _dp, _dp, _dp, _dp, C.c_int, _dp]),
     'pem_coupled_f32_dev': (C.c_int, [_sz, C.c_float, C.c_float, _dp, _sz, _dp, _sz, _dp, _dp]),

@@ -473,16 +473,16 @@ __device__ void block_sort(u64* s, int np2) {      // bitonic, np2 a power of tw
     }
 }
 
-__global__ __launch_bounds__(QBLOCK) void select_kernel(int nt, Target* __restrict__ tg, const u64* __restrict__ cand) {
+// x_(rank) of the keys list(0) .. list(len - 1) that lie in [0, top], by one workgroup: sorted in LDS when they fit, narrowed
+// by 1024-bin histograms over the list itself until they do (heavy ties) or one key is left.  `list` is any accessor: the
+// contiguous candidate list of the single-GPU path, or the padded per-rank pieces of the sharded one (padding = ~0 > top).
+template <class List>
+__device__ u64 select_from(const List& list, u64 len, u64 rank, u64 top) {
     __shared__ u64 keys[SORT_CAP];
     __shared__ unsigned hist[1024];
     __shared__ u64 s_lo, s_hi, s_cnt, s_rank;
     __shared__ int s_bin;
-    Target& T = tg[blockIdx.x];
-    if (T.done) return;
-    const u64* list = cand + T.offset;
-    const u64 len = T.count;
-    u64 lo = 0, hi = ~0ull, rank = T.rank;
+    u64 lo = 0, hi = top;
     for (;;) {
         // the keys of the list inside [lo, hi]: how many, their smallest and largest
         if (threadIdx.x == 0) {
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(QBLOCK) void select_kernel(int nt, Target* __restri
         __syncthreads();
         u64 mn = ~0ull, mx = 0, cnt = 0;
         for (u64 i = threadIdx.x; i < len; i += QBLOCK) {
-            const u64 k = list[i];
+            const u64 k = list(i);
             if (k >= lo && k <= hi) {
                 mn = k < mn ? k : mn;
                 mx = k > mx ? k : mx;
@@ -510,13 +510,7 @@ __global__ __launch_bounds__(QBLOCK) void select_kernel(int nt, Target* __restri
         hi = s_hi;
         const u64 inside = s_cnt;
         __syncthreads();
-        if (lo >= hi) {                        // one value left (or, defensively, nothing)
-            if (threadIdx.x == 0) {
-                T.answer = lo;
-                T.done = 1;
-            }
-            return;
-        }
+        if (lo >= hi) return lo;               // one value left (or, defensively, nothing)
         if (inside <= SORT_CAP) {
             int np2 = 1;
             while (np2 < (int)inside) np2 <<= 1;
@@ -524,23 +518,21 @@ __global__ __launch_bounds__(QBLOCK) void select_kernel(int nt, Target* __restri
             for (int i = threadIdx.x; i < np2; i += QBLOCK) keys[i] = ~0ull;
             __syncthreads();
             for (u64 i = threadIdx.x; i < len; i += QBLOCK) {
-                const u64 k = list[i];
+                const u64 k = list(i);
                 if (k >= lo && k <= hi) keys[atomicAdd(&s_cnt, 1ull)] = k;
             }
             __syncthreads();
             block_sort(keys, np2);
-            if (threadIdx.x == 0) {
-                T.answer = keys[rank < inside ? rank : inside - 1];
-                T.done = 1;
-            }
-            return;
+            const u64 r = keys[rank < inside ? rank : inside - 1];
+            __syncthreads();
+            return r;
         }
         // too long for LDS: 1024-bin histogram over [lo, hi], keep the bin that holds the rank
         for (int i = threadIdx.x; i < 1024; i += QBLOCK) hist[i] = 0;
         __syncthreads();
         const double inv = 1024.0 / ((double)(hi - lo) + 1.0);
         for (u64 i = threadIdx.x; i < len; i += QBLOCK) {
-            const u64 k = list[i];
+            const u64 k = list(i);
             if (k >= lo && k <= hi) atomicAdd(&hist[bin_of_d(k, lo, inv, 1024)], 1u);
         }
         __syncthreads();
@@ -566,7 +558,7 @@ __global__ __launch_bounds__(QBLOCK) void select_kernel(int nt, Target* __restri
         mn = ~0ull;
         mx = 0;
         for (u64 i = threadIdx.x; i < len; i += QBLOCK) {
-            const u64 k = list[i];
+            const u64 k = list(i);
             if (k >= lo && k <= hi && bin_of_d(k, lo, inv, 1024) == keep) {
                 mn = k < mn ? k : mn;
                 mx = k > mx ? k : mx;
@@ -580,6 +572,17 @@ __global__ __launch_bounds__(QBLOCK) void select_kernel(int nt, Target* __restri
         lo = s_lo;
         hi = s_hi;
         __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(QBLOCK) void select_kernel(int nt, Target* __restrict__ tg, const u64* __restrict__ cand) {
+    Target& T = tg[blockIdx.x];
+    if (T.done) return;
+    const u64* list = cand + T.offset;
+    const u64 answer = select_from([list](u64 i) { return list[i]; }, T.count, T.rank, ~0ull);
+    if (threadIdx.x == 0) {
+        T.answer = answer;
+        T.done = 1;
     }
 }
 
@@ -924,3 +927,428 @@ extern "C" int pem_range_narrow_dev(int n_ranges, int bins, const uint32_t* hist
     HIP_TRY(hipGetLastError());
     return PEM_OK;
 }
+
+// ---- the sharded selection on the single-GPU selection's passes (round 3) -------------------------------------------------------
+// The level loop above narrows a key range by 64 bins per streaming pass: eleven passes for 1e7 x 91 values.  The single-GPU
+// selection needs four, and its two histograms ADD across ranks just as well: every rank runs the same passes over its own
+// rows, the per-column min / max and the two histograms are all-reduced between them (91 x 256 and 91 x 6 x 64 counters:
+// nothing on xGMI), every rank takes the same decisions, and what is left per wanted rank -- 1 / (bins1 bins2) of a column --
+// is copied out into fixed-length padded lists that are all-gathered and selected from by one workgroup per list.
+// hallthrusterpem_amd/percentiles.py drives the stages and restates them in numpy for the gloo rehearsal on the CPU.
+// State lives in plain caller-owned device arrays (so that the collectives can run on them):
+//   kmin / kmax [m] u64, has_nan [m] i32; hist1 [m][bins1] u32; hist2 [m][nt][bins2] u32;
+//   resid [m nt] u64 (in: the wanted 0-based ranks, rewritten to the rank inside the chosen bin, then sub-bin);
+//   bin1 / bin2 [m nt] i32; done [m nt] i32 + answer [m nt] u64 (constant columns are decided at once);
+//   cand [m nt][L] u64 padded with ~0, cursor [m nt] u32 (values a list was offered: > L means it overflowed).
+namespace {
+
+__device__ __forceinline__ Scale column_scale(u64 kmin, u64 kmax, int bins1) {      // scale_columns_kernel, per lane
+    Scale sc;
+    const u64 span = kmax >= kmin ? kmax - kmin : 0;
+    int shift = 0;
+    while ((span >> shift) >> 31) ++shift;
+    const u64 mult = (((u64)bins1) << 32) / ((span >> shift) + 1);
+    sc.lo = kmin;
+    sc.shift = shift;
+    sc.mult = mult > 0xffffffffull ? 0xffffffffu : (unsigned)mult;
+    return sc;
+}
+
+__global__ void qsel_init_kernel(int m, u64* kmin, u64* kmax, int* has_nan) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < m) {
+        kmin[c] = ~0ull;
+        kmax[c] = 0ull;
+        has_nan[c] = 0;
+    }
+}
+
+template <int NC>
+__global__ __launch_bounds__(QBLOCK) void qsel_minmax_kernel(long long n, int m, size_t ld, const double* __restrict__ data, u64* __restrict__ kmin,
+                                                              u64* __restrict__ kmax, int* __restrict__ has_nan) {
+    const Lanes L(m, threadIdx.x & 63);
+    u64 lo[NC], hi[NC];
+    int nan[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        lo[j] = ~0ull;
+        hi[j] = 0ull;
+        nan[j] = 0;
+    }
+    stream_values<NC>(n, m, ld, data, L, [&](int j, int, double x) {
+        if (x != x) nan[j] = 1;
+        else {
+            const u64 k = key_of(x);
+            lo[j] = k < lo[j] ? k : lo[j];
+            hi[j] = k > hi[j] ? k : hi[j];
+        }
+    });
+    __shared__ u64 s_lo[64 * MAX_NC], s_hi[64 * MAX_NC];
+    __shared__ int s_nan[64 * MAX_NC];
+    for (int c = threadIdx.x; c < m; c += QBLOCK) {
+        s_lo[c] = ~0ull;
+        s_hi[c] = 0ull;
+        s_nan[c] = 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const int c = L.col0 + 64 * j;
+        if (L.active && c < m) {
+            if (lo[j] <= hi[j]) {
+                atomicMin(&s_lo[c], lo[j]);
+                atomicMax(&s_hi[c], hi[j]);
+            }
+            if (nan[j]) atomicOr(&s_nan[c], 1);
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < m; c += QBLOCK) {
+        if (s_lo[c] <= s_hi[c]) {
+            atomicMin(&kmin[c], s_lo[c]);
+            atomicMax(&kmax[c], s_hi[c]);
+        }
+        if (s_nan[c]) atomicOr(&has_nan[c], 1);
+    }
+}
+
+template <int NC>
+__global__ __launch_bounds__(QBLOCK) void qsel_hist1_kernel(long long n, int m, size_t ld, const double* __restrict__ data, const u64* __restrict__ kmin,
+                                                             const u64* __restrict__ kmax, int bins1, unsigned* __restrict__ hist1) {
+    extern __shared__ unsigned lds_hist[];
+    for (int i = threadIdx.x; i < m * bins1; i += QBLOCK) lds_hist[i] = 0;
+    __syncthreads();
+    const Lanes L(m, threadIdx.x & 63);
+    Scale sc[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const int c = L.col0 + 64 * j;
+        const bool on = L.active && c < m;
+        sc[j] = on ? column_scale(kmin[c], kmax[c], bins1) : column_scale(1, 0, bins1);
+    }
+    stream_values<NC>(n, m, ld, data, L, [&](int j, int c, double x) {
+        if (x == x) {
+            unsigned frac;
+            atomicAdd(&lds_hist[c * bins1 + bin_of(key_of(x), sc[j], frac)], 1u);
+        }
+    });
+    __syncthreads();
+    for (int i = threadIdx.x; i < m * bins1; i += QBLOCK) {
+        const unsigned v = lds_hist[i];
+        if (v) atomicAdd(&hist1[i], v);
+    }
+}
+
+// one wave per (column, target): the bin of the (all-reduced) histogram that holds the wanted rank
+__global__ __launch_bounds__(64) void qsel_decide1_kernel(int nt, const u64* __restrict__ kmin, const u64* __restrict__ kmax,
+                                                           const unsigned* __restrict__ hist1, int bins1, u64* __restrict__ resid,
+                                                           int* __restrict__ bin1, int* __restrict__ done, u64* __restrict__ answer) {
+    const int i = blockIdx.x, lane = threadIdx.x, c = i / nt;
+    if (kmin[c] >= kmax[c]) {                 // a constant column, or one without a value (its result is NaN anyway)
+        if (lane == 0) {
+            done[i] = 1;
+            answer[i] = kmin[c];
+            bin1[i] = -1;
+        }
+        return;
+    }
+    const Found f = find_bin(hist1 + (size_t)c * bins1, bins1, resid[i], lane);
+    if (lane == 0) {
+        done[i] = 0;
+        bin1[i] = f.bin;
+        resid[i] -= f.before;
+    }
+}
+
+template <int NC, int NT>
+__global__ __launch_bounds__(QBLOCK) void qsel_hist2_kernel(long long n, int m, size_t ld, const double* __restrict__ data, const u64* __restrict__ kmin,
+                                                             const u64* __restrict__ kmax, const int* __restrict__ bin1, int bins1, int bins2,
+                                                             unsigned* __restrict__ hist2) {
+    extern __shared__ unsigned lds_hist[];
+    for (int i = threadIdx.x; i < m * NT * bins2; i += QBLOCK) lds_hist[i] = 0;
+    __syncthreads();
+    const Lanes L(m, threadIdx.x & 63);
+    Scale sc[NC];
+    int tb[NC][NT];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const int c = L.col0 + 64 * j;
+        const bool on = L.active && c < m;
+        sc[j] = on ? column_scale(kmin[c], kmax[c], bins1) : column_scale(1, 0, bins1);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            // targets of a column often share a bin: each DISTINCT bin is counted once, under the first target that has it
+            int b = on ? bin1[c * NT + t] : -1;
+#pragma unroll
+            for (int u = 0; u < t; ++u)
+                if (on && bin1[c * NT + u] == b) b = -1;
+            tb[j][t] = b;
+        }
+    }
+    stream_values<NC>(n, m, ld, data, L, [&](int j, int c, double x) {
+        if (x == x) {
+            unsigned frac;
+            const int b = bin_of(key_of(x), sc[j], frac);
+            int hit = -1;                                   // at most one target holds a given bin (deduplicated above): one branch, not NT
+#pragma unroll
+            for (int t = 0; t < NT; ++t) hit = tb[j][t] == b ? t : hit;
+            if (hit >= 0) atomicAdd(&lds_hist[(c * NT + hit) * bins2 + subbin_of(frac, bins2)], 1u);
+        }
+    });
+    __syncthreads();
+    for (int i = threadIdx.x; i < m * NT * bins2; i += QBLOCK) {
+        const unsigned v = lds_hist[i];
+        if (v) atomicAdd(&hist2[i], v);
+    }
+}
+
+// one wave per (column, target): the sub-bin that holds the rank, from the all-reduced counts; how many of THIS rank's values
+// sit in it, from the local ones (the histogram of a bin is kept under the column's first target that has it)
+__global__ __launch_bounds__(64) void qsel_decide2_kernel(int nt, const unsigned* __restrict__ hist2, const unsigned* __restrict__ hist2_local,
+                                                           int bins2, const int* __restrict__ bin1, const int* __restrict__ done,
+                                                           u64* __restrict__ resid, int* __restrict__ bin2, u64* __restrict__ count,
+                                                           unsigned* __restrict__ count_local) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const int c = i / nt, t = i - c * nt;
+    if (done[i]) {
+        if (lane == 0) {
+            bin2[i] = -1;
+            count[i] = 0;
+            count_local[i] = 0;
+        }
+        return;
+    }
+    int first = t;
+    for (int u = t - 1; u >= 0; --u)
+        if (!done[c * nt + u] && bin1[c * nt + u] == bin1[i]) first = u;
+    const Found f = find_bin(hist2 + (size_t)(c * nt + first) * bins2, bins2, resid[i], lane);
+    if (lane == 0) {
+        bin2[i] = f.bin;
+        resid[i] -= f.before;
+        count[i] = f.count;
+        count_local[i] = hist2_local[(size_t)(c * nt + first) * bins2 + f.bin];
+    }
+}
+
+// this rank's values of every wanted (bin, sub-bin), one padded list per (column, target) -- only the first target of a column
+// with a given pair collects (the others read its list)
+template <int NC, int NT>
+__global__ __launch_bounds__(QBLOCK) void qsel_compact_kernel(long long n, int m, size_t ld, const double* __restrict__ data, const u64* __restrict__ kmin,
+                                                               const u64* __restrict__ kmax, const int* __restrict__ bin1, const int* __restrict__ bin2,
+                                                               const int* __restrict__ done, int bins1, int bins2, unsigned list_len,
+                                                               u64* __restrict__ cand, unsigned* __restrict__ cursor) {
+    const Lanes L(m, threadIdx.x & 63);
+    Scale sc[NC];
+    int tb1[NC][NT], tb2[NC][NT];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const int c = L.col0 + 64 * j;
+        const bool on = L.active && c < m;
+        sc[j] = on ? column_scale(kmin[c], kmax[c], bins1) : column_scale(1, 0, bins1);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            bool own = on && !done[c * NT + t];
+#pragma unroll
+            for (int u = 0; u < t; ++u)
+                if (own && !done[c * NT + u] && bin1[c * NT + u] == bin1[c * NT + t] && bin2[c * NT + u] == bin2[c * NT + t]) own = false;
+            tb1[j][t] = own ? bin1[c * NT + t] : -1;
+            tb2[j][t] = own ? bin2[c * NT + t] : -1;
+        }
+    }
+    stream_values<NC>(n, m, ld, data, L, [&](int j, int c, double x) {
+        if (x == x) {
+            const u64 k = key_of(x);
+            unsigned frac;
+            const int b = bin_of(k, sc[j], frac);
+            const int sb = subbin_of(frac, bins2);
+            int hit = -1;                                   // list owners have distinct (bin, sub-bin) pairs: at most one matches
+#pragma unroll
+            for (int t = 0; t < NT; ++t) hit = (tb1[j][t] == b && tb2[j][t] == sb) ? t : hit;
+            if (hit >= 0) {
+                const unsigned at = atomicAdd(&cursor[c * NT + hit], 1u);
+                if (at < list_len) cand[(size_t)(c * NT + hit) * list_len + at] = k;
+            }
+        }
+    });
+}
+
+// one workgroup per (column, target): x_(resid) of the union of every rank's list of its (bin, sub-bin)
+__global__ __launch_bounds__(QBLOCK) void qsel_select_kernel(int nt, int world, unsigned list_len, size_t rank_stride, const u64* __restrict__ gathered,
+                                                              const int* __restrict__ bin1, const int* __restrict__ bin2, const int* __restrict__ done,
+                                                              const u64* __restrict__ resid, u64* __restrict__ answer) {
+    const int i = blockIdx.x;
+    if (done[i]) return;
+    const int c = i / nt, t = i - c * nt;
+    int owner = t;
+    for (int u = t - 1; u >= 0; --u)
+        if (!done[c * nt + u] && bin1[c * nt + u] == bin1[i] && bin2[c * nt + u] == bin2[i]) owner = u;
+    const u64* base = gathered + (size_t)(c * nt + owner) * list_len;
+    const u64 r = select_from([=](u64 k) { return base[(size_t)(k / list_len) * rank_stride + (size_t)(k % list_len)]; },
+                              (u64)world * list_len, resid[i], 0xfff0000000000000ull /* key of +inf: the padding lies above it */);
+    if (threadIdx.x == 0) answer[i] = r;
+}
+
+int qsel_check(const char* who, size_t n, int m, size_t ld, const void* data) {
+    if (m < 1 || m > 64 * MAX_NC) return pem::fail(PEM_ERR_INVALID_ARG, "%s: 1 <= m <= %d columns", who, 64 * MAX_NC);
+    if (ld < (size_t)m) return pem::fail(PEM_ERR_INVALID_ARG, "%s: leading dimension smaller than m", who);
+    if (n && !data) return pem::fail(PEM_ERR_INVALID_ARG, "%s: NULL data", who);
+    return pem::check_device();
+}
+
+}  // namespace
+
+extern "C" {
+
+int pem_qsel_bins(int m, int nt, int* bins1, int* bins2) {
+    if (m < 1 || m > 64 * MAX_NC || nt < 1 || nt > 2 * PEM_QUANTILE_MAX_Q || !bins1 || !bins2)
+        return pem::fail(PEM_ERR_INVALID_ARG, "pem_qsel_bins: 1 <= m <= %d, 1 <= nt <= %d", 64 * MAX_NC, 2 * PEM_QUANTILE_MAX_Q);
+    *bins1 = pow2_at_most(LDS_WORDS / m, 4096);
+    *bins2 = pow2_at_most(LDS_WORDS / (m * nt), 4096);
+    return PEM_OK;
+}
+
+int pem_qsel_minmax_f64_dev(size_t n, int m, const double* data, size_t ld, uint64_t* kmin, uint64_t* kmax, int32_t* has_nan,
+                            pem_stream_t stream) {
+    if (int rc = qsel_check("pem_qsel_minmax", n, m, ld, data)) return rc;
+    if (!kmin || !kmax || !has_nan) return pem::fail(PEM_ERR_INVALID_ARG, "pem_qsel_minmax: NULL array");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(qsel_init_kernel, dim3((m + 63) / 64), dim3(64), 0, st, m, (u64*)kmin, (u64*)kmax, (int*)has_nan);
+    if (n) {
+        const int nc = m <= 64 ? 1 : (m <= 128 ? 2 : 4);
+        const dim3 grid = stream_grid(n, m), blk(QBLOCK);
+        if (nc == 1) hipLaunchKernelGGL(qsel_minmax_kernel<1>, grid, blk, 0, st, (long long)n, m, ld, data, (u64*)kmin, (u64*)kmax, (int*)has_nan);
+        else if (nc == 2) hipLaunchKernelGGL(qsel_minmax_kernel<2>, grid, blk, 0, st, (long long)n, m, ld, data, (u64*)kmin, (u64*)kmax, (int*)has_nan);
+        else hipLaunchKernelGGL(qsel_minmax_kernel<4>, grid, blk, 0, st, (long long)n, m, ld, data, (u64*)kmin, (u64*)kmax, (int*)has_nan);
+    }
+    HIP_TRY(hipGetLastError());
+    return PEM_OK;
+}
+
+int pem_qsel_hist1_f64_dev(size_t n, int m, const double* data, size_t ld, const uint64_t* kmin, const uint64_t* kmax, int bins1,
+                           uint32_t* hist1, pem_stream_t stream) {
+    if (int rc = qsel_check("pem_qsel_hist1", n, m, ld, data)) return rc;
+    if (!kmin || !kmax || !hist1) return pem::fail(PEM_ERR_INVALID_ARG, "pem_qsel_hist1: NULL array");
+    if (bins1 < 1 || (long long)m * bins1 > LDS_WORDS) return pem::fail(PEM_ERR_INVALID_ARG, "pem_qsel_hist1: m * bins1 must not exceed %d", LDS_WORDS);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemsetAsync(hist1, 0, sizeof(uint32_t) * (size_t)m * bins1, st));
+    if (n == 0) return PEM_OK;
+    const int nc = m <= 64 ? 1 : (m <= 128 ? 2 : 4);
+    const dim3 grid = stream_grid(n, m), blk(QBLOCK);
+    const size_t lds = (size_t)m * bins1 * 4;
+#define H1(NC_)                                                                                                                  \
+    do {                                                                                                                         \
+        static pem::LdsAttrOnce attr;                                                                                            \
+        HIP_TRY(attr.ensure(reinterpret_cast<const void*>(qsel_hist1_kernel<NC_>)));                                             \
+        hipLaunchKernelGGL(qsel_hist1_kernel<NC_>, grid, blk, lds, st, (long long)n, m, ld, data, (const u64*)kmin, (const u64*)kmax, \
+                           bins1, (unsigned*)hist1);                                                                             \
+    } while (0)
+    if (nc == 1) H1(1);
+    else if (nc == 2) H1(2);
+    else H1(4);
+#undef H1
+    HIP_TRY(hipGetLastError());
+    return PEM_OK;
+}
+
+int pem_qsel_decide1_dev(int m, int nt, const uint64_t* kmin, const uint64_t* kmax, const uint32_t* hist1, int bins1, uint64_t* resid,
+                         int32_t* bin1, int32_t* done, uint64_t* answer, pem_stream_t stream) {
+    if (m < 1 || nt < 1 || bins1 < 1) return pem::fail(PEM_ERR_INVALID_ARG, "pem_qsel_decide1: need columns, targets and bins");
+    if (!kmin || !kmax || !hist1 || !resid || !bin1 || !done || !answer) return pem::fail(PEM_ERR_INVALID_ARG, "pem_qsel_decide1: NULL array");
+    if (int rc = pem::check_device()) return rc;
+    hipLaunchKernelGGL(qsel_decide1_kernel, dim3((unsigned)(m * nt)), dim3(64), 0, static_cast<hipStream_t>(stream), nt, (const u64*)kmin,
+                       (const u64*)kmax, (const unsigned*)hist1, bins1, (u64*)resid, (int*)bin1, (int*)done, (u64*)answer);
+    HIP_TRY(hipGetLastError());
+    return PEM_OK;
+}
+
+int pem_qsel_hist2_f64_dev(size_t n, int m, const double* data, size_t ld, const uint64_t* kmin, const uint64_t* kmax, int nt,
+                           const int32_t* bin1, int bins1, int bins2, uint32_t* hist2, pem_stream_t stream) {
+    if (int rc = qsel_check("pem_qsel_hist2", n, m, ld, data)) return rc;
+    if (nt != 2 && nt != 4 && nt != 6) return pem::fail(PEM_ERR_INVALID_ARG, "pem_qsel_hist2: 2, 4 or 6 targets per column");
+    if (!kmin || !kmax || !bin1 || !hist2) return pem::fail(PEM_ERR_INVALID_ARG, "pem_qsel_hist2: NULL array");
+    if (bins1 < 1 || bins2 < 1 || (long long)m * nt * bins2 > LDS_WORDS)
+        return pem::fail(PEM_ERR_INVALID_ARG, "pem_qsel_hist2: m * nt * bins2 must not exceed %d", LDS_WORDS);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemsetAsync(hist2, 0, sizeof(uint32_t) * (size_t)m * nt * bins2, st));
+    if (n == 0) return PEM_OK;
+    const int nc = m <= 64 ? 1 : (m <= 128 ? 2 : 4);
+    const dim3 grid = stream_grid(n, m), blk(QBLOCK);
+    const size_t lds = (size_t)m * nt * bins2 * 4;
+#define H2(NC_, NT_)                                                                                                               \
+    do {                                                                                                                           \
+        static pem::LdsAttrOnce attr;                                                                                              \
+        HIP_TRY(attr.ensure(reinterpret_cast<const void*>(qsel_hist2_kernel<NC_, NT_>)));                                          \
+        hipLaunchKernelGGL((qsel_hist2_kernel<NC_, NT_>), grid, blk, lds, st, (long long)n, m, ld, data, (const u64*)kmin, (const u64*)kmax, \
+                           (const int*)bin1, bins1, bins2, (unsigned*)hist2);                                                      \
+    } while (0)
+#define H2_NT(NC_)                       \
+    do {                                 \
+        if (nt == 2) H2(NC_, 2);         \
+        else if (nt == 4) H2(NC_, 4);    \
+        else H2(NC_, 6);                 \
+    } while (0)
+    if (nc == 1) H2_NT(1);
+    else if (nc == 2) H2_NT(2);
+    else H2_NT(4);
+#undef H2_NT
+#undef H2
+    HIP_TRY(hipGetLastError());
+    return PEM_OK;
+}
+
+int pem_qsel_decide2_dev(int m, int nt, const uint32_t* hist2, const uint32_t* hist2_local, int bins2, const int32_t* bin1, const int32_t* done,
+                         uint64_t* resid, int32_t* bin2, uint64_t* count, uint32_t* count_local, pem_stream_t stream) {
+    if (m < 1 || nt < 1 || bins2 < 1) return pem::fail(PEM_ERR_INVALID_ARG, "pem_qsel_decide2: need columns, targets and bins");
+    if (!hist2 || !hist2_local || !bin1 || !done || !resid || !bin2 || !count || !count_local)
+        return pem::fail(PEM_ERR_INVALID_ARG, "pem_qsel_decide2: NULL array");
+    if (int rc = pem::check_device()) return rc;
+    hipLaunchKernelGGL(qsel_decide2_kernel, dim3((unsigned)(m * nt)), dim3(64), 0, static_cast<hipStream_t>(stream), nt, (const unsigned*)hist2,
+                       (const unsigned*)hist2_local, bins2, (const int*)bin1, (const int*)done, (u64*)resid, (int*)bin2, (u64*)count,
+                       (unsigned*)count_local);
+    HIP_TRY(hipGetLastError());
+    return PEM_OK;
+}
+
+int pem_qsel_compact_f64_dev(size_t n, int m, const double* data, size_t ld, const uint64_t* kmin, const uint64_t* kmax, int nt,
+                             const int32_t* bin1, const int32_t* bin2, const int32_t* done, int bins1, int bins2, uint32_t list_len,
+                             uint64_t* cand, uint32_t* cursor, pem_stream_t stream) {
+    if (int rc = qsel_check("pem_qsel_compact", n, m, ld, data)) return rc;
+    if (nt != 2 && nt != 4 && nt != 6) return pem::fail(PEM_ERR_INVALID_ARG, "pem_qsel_compact: 2, 4 or 6 targets per column");
+    if (!kmin || !kmax || !bin1 || !bin2 || !done || !cand || !cursor || list_len < 1) return pem::fail(PEM_ERR_INVALID_ARG, "pem_qsel_compact: bad arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemsetAsync(cand, 0xff, sizeof(uint64_t) * (size_t)m * nt * list_len, st));       // padding: ~0, above every key
+    HIP_TRY(hipMemsetAsync(cursor, 0, sizeof(uint32_t) * (size_t)m * nt, st));
+    if (n == 0) return PEM_OK;
+    const int nc = m <= 64 ? 1 : (m <= 128 ? 2 : 4);
+    const dim3 grid = stream_grid(n, m), blk(QBLOCK);
+#define CP(NC_, NT_)                                                                                                                  \
+    hipLaunchKernelGGL((qsel_compact_kernel<NC_, NT_>), grid, blk, 0, st, (long long)n, m, ld, data, (const u64*)kmin, (const u64*)kmax, \
+                       (const int*)bin1, (const int*)bin2, (const int*)done, bins1, bins2, (unsigned)list_len, (u64*)cand, (unsigned*)cursor)
+#define CP_NT(NC_)                       \
+    do {                                 \
+        if (nt == 2) CP(NC_, 2);         \
+        else if (nt == 4) CP(NC_, 4);    \
+        else CP(NC_, 6);                 \
+    } while (0)
+    if (nc == 1) CP_NT(1);
+    else if (nc == 2) CP_NT(2);
+    else CP_NT(4);
+#undef CP_NT
+#undef CP
+    HIP_TRY(hipGetLastError());
+    return PEM_OK;
+}
+
+int pem_qsel_select_dev(int m, int nt, int world, uint32_t list_len, const uint64_t* gathered, const int32_t* bin1, const int32_t* bin2,
+                        const int32_t* done, const uint64_t* resid, uint64_t* answer, pem_stream_t stream) {
+    if (m < 1 || nt < 1 || world < 1 || list_len < 1) return pem::fail(PEM_ERR_INVALID_ARG, "pem_qsel_select: need columns, targets, ranks and a list length");
+    if (!gathered || !bin1 || !bin2 || !done || !resid || !answer) return pem::fail(PEM_ERR_INVALID_ARG, "pem_qsel_select: NULL array");
+    if (int rc = pem::check_device()) return rc;
+    hipLaunchKernelGGL(qsel_select_kernel, dim3((unsigned)(m * nt)), dim3(QBLOCK), 0, static_cast<hipStream_t>(stream), nt, world,
+                       (unsigned)list_len, (size_t)m * nt * list_len, (const u64*)gathered, (const int*)bin1, (const int*)bin2, (const int*)done,
+                       (const u64*)resid, (u64*)answer);
+    HIP_TRY(hipGetLastError());
+    return PEM_OK;
+}
+
+}  // extern "C"

@@ -310,6 +310,42 @@ int pem_range_hist_f64_dev(size_t n, int m, const double* data, size_t ld, int n
 int pem_range_narrow_dev(int n_ranges, int bins, const uint32_t* hist, uint64_t* klo, uint64_t* khi, int64_t* resid,
                          pem_stream_t stream);
 
+/* The sharded selection on the single-GPU selection's passes (round 3; the percentiles of scripts/gen_data.py:163-168 and
+ * scripts/pem_v0/monte_carlo.py:363-658 over samples that live on several GPUs).  Every rank runs the same stages over its own
+ * rows; hallthrusterpem_amd/percentiles.py all-reduces kmin / kmax / has_nan (MIN / MAX), hist1 and hist2 (SUM) between them and
+ * all-gathers the padded candidate lists, so that every rank takes the same decisions: four streaming passes instead of the
+ * eleven levels of pem_range_hist.  All arrays on the device, caller-owned; nt = 2 nq targets per column (the two order
+ * statistics of each of nq <= 3 quantiles); nothing here synchronises the stream.
+ *   pem_qsel_bins      bins1 / bins2 the histograms use for m columns and nt targets (pure arithmetic: LDS-bound powers of two)
+ *   pem_qsel_minmax    kmin / kmax [m]: smallest / largest key of each column (kmin > kmax: no value), has_nan [m]
+ *   pem_qsel_hist1     hist1[m][bins1] over [kmin, kmax] (the all-reduced ones): bin = floor(d mult / 2^32), d = (k - kmin) >> shift,
+ *                      shift the smallest with (kmax - kmin) >> shift < 2^31, mult = min(2^32 - 1, floor(2^32 bins1 / (((kmax - kmin) >> shift) + 1)))
+ *   pem_qsel_decide1   per (column, target): bin1 = the bin of the summed hist1 that holds resid (in: the wanted 0-based rank),
+ *                      resid <- rank inside that bin; a column with kmin >= kmax is done at once (answer = kmin)
+ *   pem_qsel_hist2     hist2[m][nt][bins2]: sub-bins (floor(frac bins2 / 2^32), frac = low word of d mult) of every target's bin1;
+ *                      a bin shared by several targets of a column is counted under the first of them
+ *   pem_qsel_decide2   bin2 from the summed hist2, resid <- rank inside it, count = values of all ranks in it, count_local = this
+ *                      rank's (read from hist2_local, the rank's own counts)
+ *   pem_qsel_compact   this rank's keys of every (bin1, bin2) into cand[m nt][list_len], padded with ~0; cursor[m nt] = values
+ *                      offered (> list_len: the list overflowed); shared pairs are collected once, under the first target
+ *   pem_qsel_select    answer[m nt] = the key of rank resid in the union of the `world` gathered lists (gathered[world][m nt][list_len]) */
+int pem_qsel_bins(int m, int nt, int* bins1, int* bins2);
+int pem_qsel_minmax_f64_dev(size_t n, int m, const double* data, size_t ld, uint64_t* kmin, uint64_t* kmax, int32_t* has_nan,
+                            pem_stream_t stream);
+int pem_qsel_hist1_f64_dev(size_t n, int m, const double* data, size_t ld, const uint64_t* kmin, const uint64_t* kmax, int bins1,
+                           uint32_t* hist1, pem_stream_t stream);
+int pem_qsel_decide1_dev(int m, int nt, const uint64_t* kmin, const uint64_t* kmax, const uint32_t* hist1, int bins1, uint64_t* resid,
+                         int32_t* bin1, int32_t* done, uint64_t* answer, pem_stream_t stream);
+int pem_qsel_hist2_f64_dev(size_t n, int m, const double* data, size_t ld, const uint64_t* kmin, const uint64_t* kmax, int nt,
+                           const int32_t* bin1, int bins1, int bins2, uint32_t* hist2, pem_stream_t stream);
+int pem_qsel_decide2_dev(int m, int nt, const uint32_t* hist2, const uint32_t* hist2_local, int bins2, const int32_t* bin1,
+                         const int32_t* done, uint64_t* resid, int32_t* bin2, uint64_t* count, uint32_t* count_local, pem_stream_t stream);
+int pem_qsel_compact_f64_dev(size_t n, int m, const double* data, size_t ld, const uint64_t* kmin, const uint64_t* kmax, int nt,
+                             const int32_t* bin1, const int32_t* bin2, const int32_t* done, int bins1, int bins2, uint32_t list_len,
+                             uint64_t* cand, uint32_t* cursor, pem_stream_t stream);
+int pem_qsel_select_dev(int m, int nt, int world, uint32_t list_len, const uint64_t* gathered, const int32_t* bin1, const int32_t* bin2,
+                        const int32_t* done, const uint64_t* resid, uint64_t* answer, pem_stream_t stream);
+
 /* ---- fused Monte-Carlo evaluation -----------------------------------------------------------------
  * sample_inputs + predict of scripts/gen_data.py:238-239 in ONE launch: the 15 coupled inputs of global samples
  * first_index .. first_index+n-1 are generated in registers from the counter-based design (kind/a/b as for

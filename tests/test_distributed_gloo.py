@@ -179,10 +179,17 @@ def _percentile_worker(rank, world, port, out_dir):
         edges = [0, 17_000, n] if world == 2 else [0, 0, 12_345, n]          # ragged shards; world 3: rank 0 holds NO rows
         mine = a[edges[rank]:edges[rank + 1]]
         for pcts in ([25.0, 75.0], [5.0, 50.0, 95.0], 50.0, [0.0, 100.0, 33.3, 99.99, 1e-3]):
-            got = P.sharded_percentiles(lambda: P.local_minmax_numpy(mine), lambda lo, hi, b: P.local_hist_numpy(mine, lo, hi, b),
-                                        mine.shape[0], m, pcts)
             want = np.percentile(a, pcts, axis=0)
-            assert got.shape == np.shape(want) and np.array_equal(got, want, equal_nan=True), (rank, pcts)
+            for method in ('select', 'levels'):
+                got = P.column_percentiles_numpy(mine, pcts, method=method)
+                assert got.shape == np.shape(want) and np.array_equal(got, want, equal_nan=True), (rank, pcts, method)
+        # ties heavier than a candidate list may be long: the selection hands the pass to the level loop and still equals numpy
+        keep, P.LIST_CAP = P.LIST_CAP, 64
+        try:
+            got = P.column_percentiles_numpy(mine, [5.0, 50.0, 95.0])
+            assert np.array_equal(got, np.percentile(a, [5.0, 50.0, 95.0], axis=0), equal_nan=True), rank
+        finally:
+            P.LIST_CAP = keep
         Path(out_dir, f'ok{rank}').write_text('ok')
     finally:
         dist.destroy_process_group()
@@ -190,8 +197,29 @@ def _percentile_worker(rank, world, port, out_dir):
 
 @pytest.mark.parametrize('world', [2, 3])
 def test_sharded_percentiles_equal_numpy_on_the_union_of_the_shards(tmp_path, world):
-    """hallthrusterpem_amd.percentiles.sharded_percentiles: histograms all-reduced level by level (MIN / MAX of the keys, SUM of
-    the counts) until every wanted rank's range is one key -- np.percentile of ALL rows bit for bit on every rank, with a
-    numpy restatement of the device histogram as the local operation (the device kernel is held to it in test_quantiles.py)."""
+    """hallthrusterpem_amd.percentiles.sharded_percentiles on ragged shards (one rank without rows, a NaN on one rank only, 30 %
+    ties, a constant column): the four-pass selection -- min / max and two histograms all-reduced, padded candidate lists
+    all-gathered -- and the level loop it falls back to, both equal to np.percentile of ALL rows bit for bit on every rank.
+    Every stage runs on its numpy restatement here (the device kernels are held to it stage by stage in test_quantiles.py)."""
     mp.spawn(_percentile_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f'ok{r}').exists() for r in range(world))
+
+
+def test_percentiles_of_more_columns_than_one_kernel_call_takes():
+    """More than 256 columns go through the kernels 256 at a time, so the bins per level are bounded by the CHUNK's width: sized
+    from the whole width (round 2) they came out as 1 for m > 3072 with three percentiles, the ranges never narrowed and the
+    level loop gave up after 80 passes.  No process group: one rank."""
+    from hallthrusterpem_amd import percentiles as P
+    assert P.level_bins(256, 6) == 16 and P.level_bins(91, 6) == 64 and P.level_bins(256, 2) == 64
+    rng = np.random.default_rng(4)
+    a = rng.standard_normal((50, 3100))
+    want = np.percentile(a, [5.0, 50.0, 95.0], axis=0)
+    cols = P.NumpyColumns(a)
+    kmin, kmax, _ = cols.minmax()
+    rp, rn, _ = P.linear_ranks(50, [5.0, 50.0, 95.0])
+    ranks = np.stack([rp, rn], axis=1).reshape(-1)
+    # the host-level loop exactly as DeviceColumns.levels_pass drives it for wide arrays: bins from the chunk width
+    keys = P.narrow_by_levels(lambda lo, hi, b: P.local_hist_numpy(a, lo, hi, b), ranks, kmin, kmax, chunk_columns=256)
+    assert np.array_equal(np.sort(a, axis=0)[ranks].T, P.value_of(keys))
+    for method in ('select', 'levels'):
+        assert np.array_equal(P.column_percentiles_numpy(a, [5.0, 50.0, 95.0], method=method), want)

@@ -84,8 +84,8 @@ def test_percentile_bands_of_a_forward_uq_campaign():
 
 
 def test_range_histogram_and_key_minmax_equal_their_numpy_restatement():
-    """pem_key_minmax_f64_dev / pem_range_hist_f64_dev (the local operations of the multi-rank percentiles) against
-    percentiles.local_minmax_numpy / local_hist_numpy -- the restatement the gloo tests run the level logic on."""
+    """pem_qsel_minmax_f64_dev / pem_range_hist_f64_dev (the local operations of the level loop the sharded percentiles fall back
+    to) against percentiles.local_minmax_numpy / local_hist_numpy -- the restatement the gloo tests run the level logic on."""
     import torch
     from hallthrusterpem_amd import percentiles as P
     rng = np.random.default_rng(8)
@@ -111,6 +111,79 @@ def test_range_histogram_and_key_minmax_equal_their_numpy_restatement():
             assert np.array_equal(got, P.local_hist_numpy(a, lo, hi, bins)), (n, m, nr)
 
 
+def test_selection_stages_equal_their_numpy_restatement():
+    """Every stage of the sharded selection (pem_qsel_hist1 / decide1 / hist2 / decide2 / compact / select) against the numpy
+    restatement the gloo rehearsal runs (percentiles.NumpyColumns, decide1, decide2, select_lists), on data with ties, infinities,
+    a constant column, a NaN, for 2 / 4 / 6 targets and 1 ... 200 columns -- and with the lists of two "ranks" put side by side."""
+    import ctypes as C
+    import torch
+    from hallthrusterpem_amd import _lib, percentiles as P
+    lib = _lib.load()
+    rng = np.random.default_rng(21)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr())                                   # noqa: E731
+    for n, m, pcts in ((60_000, 91, [5.0, 50.0, 95.0]), (20_000, 7, [25.0, 75.0]), (9000, 1, [50.0]), (5000, 200, [1.0, 99.0]), (300, 64, [0.0, 100.0, 50.0])):
+        a = rng.lognormal(0.0, 3.0, (n, m)) * rng.choice([-1.0, 1.0], (n, m))
+        a[rng.random(n) < 0.25, 0] = 1e-20
+        if m > 3:
+            a[:, 2] = 4.5
+            a[::11, 3] = np.inf
+            a[5, 1] = np.nan
+        ref, dev = P.NumpyColumns(a), P.DeviceColumns(torch.from_numpy(a).cuda())
+        kmin, kmax, nan = ref.minmax()
+        dmin, dmax, dnan = dev.minmax()
+        assert np.array_equal(kmin, dmin) and np.array_equal(kmax, dmax) and np.array_equal(nan, dnan)
+        rp, rn, _ = P.linear_ranks(n, pcts)
+        ranks = np.stack([rp, rn], axis=1).reshape(-1)
+        nt = ranks.size
+        bins1, bins2 = P.qsel_bins(m, nt)
+        b1, b2 = C.c_int(0), C.c_int(0)
+        _lib.check(lib.pem_qsel_bins(m, nt, C.byref(b1), C.byref(b2)))
+        assert (b1.value, b2.value) == (bins1, bins2)
+        i32, i64 = dict(dtype=torch.int32, device='cuda'), dict(dtype=torch.int64, device='cuda')
+        kmn, kmx = (torch.from_numpy(k.view(np.int64).copy()).cuda() for k in (kmin, kmax))
+        # stage 1
+        h1 = torch.empty((m, bins1), **i32)
+        _lib.check(lib.pem_qsel_hist1_f64_dev(n, m, p(dev.flat), m, p(kmn), p(kmx), bins1, p(h1), st))
+        want_h1 = ref.hist1(kmin, kmax, bins1)
+        assert np.array_equal(h1.cpu().numpy(), want_h1)
+        resid = torch.from_numpy(np.broadcast_to(ranks, (m, nt)).astype(np.int64).copy()).cuda()
+        bin1, done, ans = torch.empty((m, nt), **i32), torch.empty((m, nt), **i32), torch.zeros((m, nt), **i64)
+        _lib.check(lib.pem_qsel_decide1_dev(m, nt, p(kmn), p(kmx), p(h1), bins1, p(resid), p(bin1), p(done), p(ans), st))
+        w_bin1, w_done, w_ans, w_resid = P.decide1(kmin, kmax, want_h1, np.broadcast_to(ranks, (m, nt)).astype(np.int64))
+        live = ~w_done
+        assert np.array_equal(done.cpu().numpy().astype(bool), w_done) and np.array_equal(bin1.cpu().numpy(), w_bin1)
+        assert np.array_equal(resid.cpu().numpy()[live], w_resid[live]) and np.array_equal(ans.cpu().numpy().view(np.uint64)[w_done], w_ans[w_done])
+        # stage 2
+        h2 = torch.empty((m, nt, bins2), **i32)
+        _lib.check(lib.pem_qsel_hist2_f64_dev(n, m, p(dev.flat), m, p(kmn), p(kmx), nt, p(bin1), bins1, bins2, p(h2), st))
+        want_h2 = ref.hist2(kmin, kmax, w_bin1, bins1, bins2)
+        assert np.array_equal(h2.cpu().numpy(), want_h2)
+        bin2, cnt, cntl = torch.empty((m, nt), **i32), torch.empty((m, nt), **i64), torch.empty((m, nt), **i32)
+        _lib.check(lib.pem_qsel_decide2_dev(m, nt, p(h2), p(h2), bins2, p(bin1), p(done), p(resid), p(bin2), p(cnt), p(cntl), st))
+        w_bin2, w_cnt, w_cntl, w_resid2 = P.decide2(want_h2, want_h2, w_bin1, w_done, w_resid)
+        assert np.array_equal(bin2.cpu().numpy(), w_bin2) and np.array_equal(cnt.cpu().numpy(), w_cnt)
+        assert np.array_equal(cntl.cpu().numpy(), w_cntl) and np.array_equal(resid.cpu().numpy()[live], w_resid2[live])
+        # stage 3: the padded lists (order inside a list is the kernel's own: compared as sets), then the selection
+        L = P._list_len(int(w_cntl.max(initial=0)))
+        cand, cur = torch.empty((m * nt, L), **i64), torch.empty(m * nt, **i32)
+        _lib.check(lib.pem_qsel_compact_f64_dev(n, m, p(dev.flat), m, p(kmn), p(kmx), nt, p(bin1), p(bin2), p(done), bins1, bins2, L, p(cand), p(cur), st))
+        w_cand, w_cur = ref.compact(kmin, kmax, w_bin1, w_bin2, w_done, bins1, bins2, L)
+        assert np.array_equal(cur.cpu().numpy().reshape(m, nt), w_cur)
+        assert np.array_equal(np.sort(cand.cpu().numpy().view(np.uint64).reshape(m, nt, L), axis=2), np.sort(w_cand, axis=2))
+        out = torch.zeros((m, nt), **i64)
+        for world in (1, 2):                   # two "ranks": the same lists twice -> the union holds every key twice
+            gathered = torch.stack([cand] * world).contiguous()
+            r2 = resid * world if world == 2 else resid
+            _lib.check(lib.pem_qsel_select_dev(m, nt, world, L, p(gathered), p(bin1), p(bin2), p(done), p(r2), p(out), st))
+            want = P.select_lists(np.stack([w_cand] * world), w_bin1, w_bin2, w_done, w_resid2 * world, w_ans)
+            ok = live & (nan == 0)[:, None]        # (a rank past a NaN column's last value has an empty list: its result is NaN anyway)
+            assert np.array_equal(out.cpu().numpy().view(np.uint64)[ok], want[ok]), (n, m, world)
+        col_sorted = np.sort(a, axis=0)
+        keep = (nan == 0)
+        assert np.array_equal(P.value_of(np.where(w_done, w_ans, want))[keep], col_sorted[ranks].T[keep])
+
+
 def test_sharded_percentiles_on_one_rank_equal_numpy():
     import torch
     from hallthrusterpem_amd.percentiles import column_percentiles_sharded
@@ -120,12 +193,26 @@ def test_sharded_percentiles_on_one_rank_equal_numpy():
     a[5, 7] = np.nan
     d = torch.from_numpy(a).cuda()
     for pcts in ([25.0, 75.0], [5.0, 50.0, 95.0], 50.0):
-        for on_device in (True, False):      # the levels decided on the device (pem_range_narrow_dev) and by the numpy restatement
-            assert np.array_equal(column_percentiles_sharded(d, pcts, on_device=on_device), np.percentile(a, pcts, axis=0), equal_nan=True)
+        for method in ('select', 'levels'):  # the four-pass selection, and the level loop it falls back to
+            assert np.array_equal(column_percentiles_sharded(d, pcts, method=method), np.percentile(a, pcts, axis=0), equal_nan=True)
+    # 20 % ties at one value: with a short cap on the candidate lists the pass is handed to the level loop, same result
+    from hallthrusterpem_amd import percentiles as P
+    keep, P.LIST_CAP = P.LIST_CAP, 256
+    try:
+        assert np.array_equal(column_percentiles_sharded(d, [5.0, 50.0, 95.0]), np.percentile(a, [5.0, 50.0, 95.0], axis=0), equal_nan=True)
+    finally:
+        P.LIST_CAP = keep
+    # ... a percentile INSIDE the tie block (40 000 equal keys in one sub-bin, more than any list may hold): the level loop again
+    assert np.array_equal(column_percentiles_sharded(d[:, 3].contiguous(), [10.0]), np.percentile(a[:, 3], [10.0]))
     s = torch.from_numpy(a[:, 0].copy()).cuda()
     assert column_percentiles_sharded(s, [10.0, 90.0]).shape == (2,) and np.array_equal(column_percentiles_sharded(s, [10.0, 90.0]), np.percentile(a[:, 0], [10.0, 90.0]))
     wide = torch.from_numpy(rng.standard_normal((3000, 300))).cuda()
-    assert np.array_equal(column_percentiles_sharded(wide, [50.0]), np.percentile(wide.cpu().numpy(), [50.0], axis=0))
+    for method in ('select', 'levels'):
+        assert np.array_equal(column_percentiles_sharded(wide, [50.0], method=method), np.percentile(wide.cpu().numpy(), [50.0], axis=0))
+    # more columns than 3072: round 2 sized the level loop's bins from the whole width and never converged
+    wider = torch.from_numpy(rng.standard_normal((50, 3100))).cuda()
+    for method in ('select', 'levels'):
+        assert np.array_equal(column_percentiles_sharded(wider, [5.0, 50.0, 95.0], method=method), np.percentile(wider.cpu().numpy(), [5.0, 50.0, 95.0], axis=0))
 
 
 def _two_rank_worker(rank, world, port, out_dir):

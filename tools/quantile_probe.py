@@ -33,10 +33,11 @@ for n, m in ((1_000_000, 91), (10_000_000, 91), (10_000_000, 1), (1_000_000, 3))
     del out, a
     torch.cuda.empty_cache()
 
-# the multi-rank form on ONE rank (every level a streaming pass + a device-to-host copy of the counts; no collective here)
+# the multi-rank form on ONE rank (no collective here): the four-pass selection, and the level loop of rounds 1-2
 from hallthrusterpem_amd.percentiles import column_percentiles_sharded
 for n in (1_250_000, 10_000_000):
     a = drivers.forward_uq(n, seed=2, keep_profile=True)['j_ion']
-    t = wall(lambda: column_percentiles_sharded(a, [5.0, 50.0, 95.0]), reps=3)
-    print(f'sharded form, one rank, n={n} m=91 percentiles [5, 50, 95]: {t * 1e3:.2f} ms', flush=True)
+    for method in ('select', 'levels'):
+        t = wall(lambda: column_percentiles_sharded(a, [5.0, 50.0, 95.0], method=method), reps=5)
+        print(f'sharded form ({method}), one rank, n={n} m=91 percentiles [5, 50, 95]: {t * 1e3:.2f} ms', flush=True)
     del a
