@@ -853,6 +853,150 @@ __global__ __launch_bounds__(BLOCK) void plume_radii_kernel(PlumeIO io, RadiiArg
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// sweep_radius arrays, RADII_SMALL < R <= RMID_MAX (tests/test_plume.py:31 uses 25): the recipe of the few-radii kernel below
+// applied to the wave-per-sample kernel above -- several samples in flight per wave, the block staged in LDS in final order,
+// 16-byte stores of whole contiguous runs.  G = 4 / 2 / 1 samples share a wave (R <= 16 / 32 / 64): lane (grp, r) owns radius
+// r of sample grp, keeps its amplitudes in registers and walks the 91 angles; the two Gaussians of a sample (91 direct exp()
+// each: the reference's literal expression, deep tail included) are read from LDS as one broadcast 16-byte word per angle.
+// What the lane produces -- b1[r] e1[k] + b2[r] e2[k] + j_cex[r], the Simpson sums of plume.py:117-123 taken angle by angle as the
+// reference takes them -- goes to an LDS tile laid out as j_ion is, `kc` rows of every sample at a time (8 KB per wave), and
+// leaves as runs of kc R contiguous doubles: one leading 8-byte store where a run starts on an odd double (the LDS copy is
+// placed with the same parity), then 1 KiB per instruction.  Against the kernel above this halves the LDS reads per value
+// (2.5 instead of 5), removes the per-value index arithmetic and never assembles a cache line from 8-byte pieces.
+// ---------------------------------------------------------------------------------------------
+// A run of `len` doubles from LDS to `dst`, the whole wave on it.  `from` has the 16-byte parity of `dst` (the LDS copy is placed
+// so).  Store instructions that cover WHOLE 128-byte lines are what the memory system wants: with every instruction straddling
+// a line boundary the same kernels run a quarter slower (block sizes 91 R x 8 bytes: 4.65 TB/s at R = 32, 3.39 at R = 33;
+// profiles/radii_mid_r03.txt).  So: the doubles up to the next line boundary as one partial instruction of 8-byte stores, then
+// 16 bytes per lane, 1 KiB per instruction, line-aligned; an odd double left at the end goes out alone.
+__device__ __forceinline__ void stream_run(const double* from, double* dst, int len, int lane) {
+    int head = (int)((0 - (reinterpret_cast<uintptr_t>(dst) >> 3)) & 15);
+    head = head < len ? head : len;
+    if (lane < head) __builtin_nontemporal_store(from[lane], dst + lane);
+    const int body = (len - head) >> 1;
+    const f64x2* s2 = reinterpret_cast<const f64x2*>(from + head);
+    f64x2* d2 = reinterpret_cast<f64x2*>(dst + head);
+    for (int i = lane; i < body; i += WAVE) stream_store(s2[i], &d2[i]);
+    if (((len - head) & 1) && lane == 0) __builtin_nontemporal_store(from[len - 1], dst + (len - 1));
+}
+
+constexpr int RMID_MAX = 64;
+constexpr int RMID_TILE = 1024;                 // doubles of staged rows per wave
+struct RadiiMidArg {
+    double r[RMID_MAX];
+};
+template <int G>
+constexpr int rmid_wave_doubles() { return G * 96 * 2 + RMID_TILE + 2; }
+
+#ifndef PEM_RMID_WAVES
+#define PEM_RMID_WAVES 3
+#endif
+template <int G>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(PEM_RMID_WAVES)))
+void plume_rmid_kernel(PlumeIO io, RadiiMidArg radii_arg, int R, int ts) {
+#pragma clang fp contract(off)
+    constexpr int LS = WAVE / G;                // lanes per sample
+    constexpr int RS = RMID_TILE / G;           // doubles of the tile per sample (even)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double* mine = reinterpret_cast<double*>(smem_raw) + (size_t)wave * rmid_wave_doubles<G>();
+    double2* E = reinterpret_cast<double2*>(mine);   // [G][96] {e1[k], e2[k]}
+    double* tile = mine + G * 96 * 2;                 // [G][RS] staged rows (16-byte aligned)
+    const int grp = lane / LS, r = lane - grp * LS;
+    const bool lane_on = r < R;
+    const int kc = (RS - 2) / R;                      // rows per chunk: kc R + 1 <= RS - 1
+    const double rad = radii_arg.r[r];
+    const unsigned long long group_mask = (LS == 64 ? ~0ull : ((1ull << LS) - 1)) << (grp * LS);
+    const long long nwaves = (long long)gridDim.x * (BLOCK / WAVE);
+    const bool have_T = io.T != nullptr;
+    const long long ntiles = (io.n + ts - 1) / ts;
+    for (long long t = blockIdx.x * (BLOCK / WAVE) + wave; t < ntiles; t += nwaves) {
+        // parameters of the tile's samples, one lane per sample (as plume_radii_kernel)
+        const long long gl = (lane < ts && t * ts + lane < io.n) ? t * ts + lane : io.n - 1;
+        const double c0_l = io.c0[gl], c1_l = io.c1[gl];
+        const PlumeSetup ps_l = plume_setup(io.P_b[gl], c1_l, io.c2[gl], io.c3[gl], io.c4[gl], io.c5[gl], io.torr2pa);
+        const double nn_l = ps_l.n_neutral, sigma_l = io.sigma[gl];
+        const double IB0_l = io.I_B0[gl];
+        const double a1_l = ps_l.a1, a2_l = ps_l.a2;
+        const double A1_l = (1.0 - c0_l) / normaliser(a1_l, 1.0 / (a1_l * a1_l), PEM_DPOLY);
+        const double A2_l = c0_l / normaliser(a2_l, 1.0 / (a2_l * a2_l), PEM_DPOLY);
+        const double thrust_l = have_T ? io.T[gl] : 0.0;
+        const int in_tile = (int)(io.n - t * ts < ts ? io.n - t * ts : ts);
+        for (int s0 = 0; s0 < in_tile; s0 += G) {
+            // the Gaussians of the group's samples: G x 91 items over the wave (every lane takes part in every shuffle)
+#pragma unroll
+            for (int it = 0; it < (G * NANG + WAVE - 1) / WAVE; ++it) {
+                const int item = it * WAVE + lane;
+                const bool valid = item < G * NANG;
+                const int gi = valid ? item / NANG : 0, k = valid ? item - gi * NANG : 0;
+                const int sm = s0 + gi < in_tile ? s0 + gi : in_tile - 1;
+                const double a1 = __shfl(a1_l, sm), a2 = __shfl(a2_l, sm);
+                const double alpha = k == NANG - 1 ? HALF_PI : (double)k * GRID_H;
+                const double t1 = alpha / a1, t2 = alpha / a2;
+                if (valid) E[gi * 96 + k] = make_double2(exp(-(t1 * t1)), exp(-(t2 * t2)));
+            }
+            // this lane's (sample, radius): amplitudes of plume.py:95-100
+            const bool smp_on = s0 + grp < in_tile;
+            const int src = smp_on ? s0 + grp : in_tile - 1;          // an idle group repeats the last sample and stores nothing
+            const long long g = t * ts + src;
+            const double a1 = __shfl(a1_l, src), A1 = __shfl(A1_l, src), A2 = __shfl(A2_l, src);
+            const double n_neutral = __shfl(nn_l, src), sigma = __shfl(sigma_l, src);
+            const double I_B0 = __shfl(IB0_l, src), thrust = __shfl(thrust_l, src);
+            const double decay = exp(-rad * n_neutral * sigma);
+            const double j_cex = I_B0 * (1.0 - decay) / (2.0 * PEM_PI * (rad * rad));
+            const double base = I_B0 * decay / (rad * rad);
+            const double b1 = base * A1, b2 = base * A2;
+            wave_lds_sync();
+            double den = 0.0, num = 0.0;
+            bool bad = false;
+            for (int k0 = 0; k0 < NANG; k0 += kc) {
+                const int rows = NANG - k0 < kc ? NANG - k0 : kc;
+                {
+                    // where this lane's run starts in j_ion: the LDS copy gets the same parity
+                    const double* gdst = io.j_ion + ((size_t)g * NANG + k0) * R;
+                    double* run = tile + grp * RS + (int)((reinterpret_cast<uintptr_t>(gdst) >> 3) & 1);
+                    if (lane_on) {
+#pragma unroll 4
+                        for (int kk = 0; kk < rows; ++kk) {
+                            const int k = k0 + kk;
+                            const double2 ee = E[grp * 96 + k];
+                            const double f = b1 * ee.x + b2 * ee.y;      // j_beam + j_scat
+                            const double ji = f + j_cex;                  // plume.py:102
+                            run[kk * R + r] = ji;
+                            den = __builtin_fma(PEM_SIMPSON_CDEN[k], f, den);
+                            num = __builtin_fma(PEM_SIMPSON_CNUM[k], f, num);
+                            bad |= ji <= 0.0;
+                        }
+                    }
+                }
+                wave_lds_sync();
+                // the runs leave one after the other, the whole wave on each
+                for (int gi = 0; gi < G; ++gi) {
+                    if (s0 + gi >= in_tile) break;
+                    double* dst = io.j_ion + ((size_t)(t * ts + s0 + gi) * NANG + k0) * R;
+                    stream_run(tile + gi * RS + (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1), dst, rows * R, lane);
+                }
+                wave_lds_sync();
+            }
+            double cos_div = num / den;   // plume.py:124-127
+            if (cos_div == __builtin_inf()) cos_div = __builtin_nan("");
+            const unsigned long long any_bad = __ballot(bad && lane_on && smp_on);
+            const bool invalid = a1 <= 0.0 || (any_bad & group_mask) != 0;      // plume.py:105
+            if (lane_on && smp_on) {
+                io.div[(size_t)g * R + r] = acos(cos_div);
+                if (have_T) io.Tc[(size_t)g * R + r] = thrust * cos_div;
+            }
+            if (smp_on && invalid) {   // plume.py:106: the whole block becomes 1e-20 (rare: a second pass over it)
+                double* blk = io.j_ion + (size_t)g * NANG * R;
+                for (int idx = r; idx < NANG * R; idx += LS) blk[idx] = 1e-20;
+            }
+            if (io.invalid && smp_on && r == 0) io.invalid[g] = (uint8_t)invalid;
+        }
+        wave_lds_sync();
+    }
+}
+
 constexpr int RADII_SMALL = 8;
 struct RadiiSmallArg {
     double r[RADII_SMALL];
@@ -1680,6 +1824,36 @@ int pem_plume_f64_dev(size_t n, int n_radii, const double* radii, double torr2pa
             default: rc = launch_rfew<8>(n, st, io, ra); break;
         }
         if (rc) return rc;
+        HIP_TRY(hipGetLastError());
+        return PEM_OK;
+    }
+    static const bool use_rmid = getenv("PEM_RADII_MID") ? atoi(getenv("PEM_RADII_MID")) != 0 : true;
+    if (use_rmid && n_radii > 16 && n_radii <= RMID_MAX) {
+        // two / one samples in flight per wave, rows staged in LDS, line-aligned 16-byte stores (plume_rmid_kernel): 3.4-5.2 TB/s
+        // of output for 17..64 radii against 3.3-4.9 for the wave-per-sample kernel below (25 radii: 3.8-4.0 against 3.2-3.35);
+        // with four samples in flight (9..16 radii) the 364 direct exp() per group weigh more than the staging saves (2.6-3.7
+        // against 2.9-3.9), so those counts stay with the kernel below (profiles/radii_mid_r03.txt)
+        RadiiMidArg ra;
+        for (int r = 0; r < RMID_MAX; ++r) ra.r[r] = r < n_radii ? radii[r] : 1.0;
+        int ts = WAVE;                             // samples per wave tile: fewer when the batch is small
+        while (ts > 8 && (n + ts - 1) / ts < 256 * 32) ts >>= 1;
+        if (const char* e = getenv("PEM_RMID_TS")) ts = atoi(e);                      // experiments
+        const size_t ntiles = (n + ts - 1) / ts;
+        int cus = 256;
+        HIP_TRY(pem::device_cus(&cus));
+        size_t blocks = (ntiles + BLOCK / WAVE - 1) / (BLOCK / WAVE);
+#define PEM_RMID_LAUNCH(G_)                                                                                         \
+    do {                                                                                                            \
+        const size_t lds = (size_t)(BLOCK / WAVE) * rmid_wave_doubles<G_>() * 8;                                    \
+        size_t per_cu = (160 * 1024) / lds;                                                                         \
+        if (per_cu > 4) per_cu = 4;                                                                                 \
+        blocks = balanced_grid(blocks, (size_t)cus * per_cu);                                                       \
+        hipLaunchKernelGGL(plume_rmid_kernel<G_>, dim3((unsigned)blocks), dim3(BLOCK), lds, st, io, ra, n_radii, ts); \
+    } while (0)
+        if (n_radii <= 16) PEM_RMID_LAUNCH(4);
+        else if (n_radii <= 32) PEM_RMID_LAUNCH(2);
+        else PEM_RMID_LAUNCH(1);
+#undef PEM_RMID_LAUNCH
         HIP_TRY(hipGetLastError());
         return PEM_OK;
     }
