@@ -63,6 +63,26 @@ struct Model32 {
     }
 };
 
+// the reference's literal 91-term sums (plume.py:99-123) for a sample outside the tabulated range.  Out of line: never taken
+// under the PEM-v0 priors, and inlined its two exp() bodies cost the rolled evaluation loop registers it does not have
+struct LiteralSums {
+    double den, num, lo;
+};
+__device__ __attribute__((noinline)) LiteralSums literal_sums(const double2* simpson, double X1a, double X2a, double j_cex, double a1, double a2) {
+#pragma clang fp contract(off)
+    using namespace pem_model;
+    double dd = 0.0, nn = 0.0, lo = __builtin_inf();
+    for (int kk = 0; kk < NANG; ++kk) {
+        const double alpha = kk == NANG - 1 ? HALF_PI : (double)kk * GRID_H;
+        const double t1 = alpha / a1, t2 = alpha / a2;
+        const double f = X1a * exp(-(t1 * t1)) + X2a * exp(-(t2 * t2));
+        lo = fmin(lo, f + j_cex);
+        dd = __builtin_fma(simpson[kk].x, f, dd);
+        nn = __builtin_fma(simpson[kk].y, f, nn);
+    }
+    return LiteralSums{dd, nn, lo};
+}
+
 struct Model64 {
     using real = double;
     static constexpr int QPOLY_DOUBLES = (PEM_NDI + PEM_NQB) * PEM_NDC * 2;
@@ -112,19 +132,10 @@ struct Model64 {
         double den = fma(base * A1, d1, (base * A2) * d2), num = fma(base * A1, n1, (base * A2) * n2);
         bool invalid = a1 <= 0.0;
         if (!plain) {
-#pragma clang fp contract(off)
-            double dd = 0.0, nn = 0.0, lo = __builtin_inf();
-            for (int kk = 0; kk < NANG; ++kk) {
-                const double alpha = kk == NANG - 1 ? HALF_PI : (double)kk * GRID_H;
-                const double t1 = alpha / a1, t2 = alpha / a2;
-                const double f = X1a * exp(-(t1 * t1)) + X2a * exp(-(t2 * t2));
-                lo = fmin(lo, f + j_cex);
-                dd = __builtin_fma(simpson[kk].x, f, dd);
-                nn = __builtin_fma(simpson[kk].y, f, nn);
-            }
-            den = dd;
-            num = nn;
-            invalid = invalid || lo <= 0.0;
+            const LiteralSums ls = literal_sums(simpson, X1a, X2a, j_cex, a1, a2);
+            den = ls.den;
+            num = ls.num;
+            invalid = invalid || ls.lo <= 0.0;
         }
         double cos_div = num / den;
         if (cos_div == __builtin_inf()) cos_div = __builtin_nan("");
@@ -199,6 +210,10 @@ void saltelli_kernel(long long n, SaltelliArg s, double torr2pa, double radius,
     __shared__ int lds_kind[NIN + 1], lds_varied[NIN + 1];
     __shared__ double lds_ab[2 * NIN];
     __shared__ double acc[4][NIN + 1][8];           // [wave][evaluation slot: 0 = the A/B statistics, 1 + j = varied input j][value]
+    // row B of the design lives in LDS, one column per input (lane-consecutive: conflict-free): an evaluation needs one value of
+    // it (all fifteen only for the B evaluation itself), and held in registers beside row A and the model's own temporaries it
+    // pushed the fp64 instantiation past 256 VGPRs (20 spilled, 96 bytes of scratch per lane)
+    __shared__ real xb_lds[NIN][256];
     __shared__ unsigned int bad[4][2];
     Model model;
     model.stage(lds_model, threadIdx.x, 256, torr2pa, radius);
@@ -222,15 +237,22 @@ void saltelli_kernel(long long n, SaltelliArg s, double torr2pa, double radius,
         const long long i = it * stride + (long long)blockIdx.x * 256 + threadIdx.x;
         const bool live = i < n;
         const unsigned long long g = s.first + (unsigned long long)(live ? i : n - 1);
-        real xa[NIN], xb[NIN];
+        real xa[NIN];
+        {
+            real xb[NIN];
+            design_row(s, lds_kind, lds_ab, g, s.stream + 1u, xb);
+#pragma unroll
+            for (int c = 0; c < NIN; ++c) xb_lds[c][threadIdx.x] = xb[c];     // read back by this lane only: no barrier
+            // (a compiler barrier: without it the stores are forwarded to the loads below and row B is back in registers)
+            asm volatile("" ::: "memory");
+        }
         design_row(s, lds_kind, lds_ab, g, s.stream, xa);
-        design_row(s, lds_kind, lds_ab, g, s.stream + 1u, xb);
         double fa[NQ] = {0.0, 0.0, 0.0}, fb[NQ] = {0.0, 0.0, 0.0};
         for (int e = 0; e < nv + 2; ++e) {                    // 0: A, 1: B, 2 + j: A with column varied[j] from B
             const int d = e >= 2 ? __builtin_amdgcn_readfirstlane(lds_varied[e - 2]) : -1;
             real x[NIN];
 #pragma unroll
-            for (int c = 0; c < NIN; ++c) x[c] = (e == 1 || c == d) ? xb[c] : xa[c];
+            for (int c = 0; c < NIN; ++c) x[c] = (e == 1 || c == d) ? xb_lds[c][threadIdx.x] : xa[c];
             const Eval o = model.eval(x);
             if (live) {
                 bad_thruster += o.bad_thruster;

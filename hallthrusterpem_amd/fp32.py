@@ -92,7 +92,7 @@ def compare_with_fp64(n: int, fill=None, seed: int = 2) -> dict:
     return report
 
 
-def saltelli_sums(design, varied, n_base: int, first_index: int = 0, radius: float = 1.0, n_blocks: int = 512, device=None, stream=None,
+def saltelli_sums(design, varied, n_base: int, first_index: int = 0, radius: float = 1.0, n_blocks: int | None = None, device=None, stream=None,
                   precision: str = 'fp32'):
     """One launch of the fused Saltelli design (`pem_saltelli_f32_dev` / `pem_saltelli_f64_dev`, csrc/pem_saltelli.hip): base
     samples first_index .. first_index+n_base-1 of `design` (rows A: its stream, B: stream + 1), `varied` = indices of the
@@ -103,6 +103,11 @@ def saltelli_sums(design, varied, n_base: int, first_index: int = 0, radius: flo
     s = torch.cuda.current_stream(dev) if stream is None else stream
     varied = np.ascontiguousarray(varied, dtype=np.int32)
     nv = int(varied.size)
+    if n_blocks is None:
+        # workgroups of 256 base samples at a time: two per CU hold the fp64 model's 198 registers per lane; the fp32 model (127)
+        # runs four waves per SIMD and keeps gaining up to eight workgroups per CU (0.38 -> 0.28 ms for the 2e7-evaluation design,
+        # profiles/saltelli_r03.txt)
+        n_blocks = 512 if precision != 'fp32' else 2048
     partial = torch.empty((n_blocks, 2 + 2 * nv, len(QOI_NAMES)), dtype=torch.float64, device=dev)
     flags = torch.empty((n_blocks, 2), dtype=torch.int64, device=dev)
     ptr = lambda arr: C.c_void_p(arr.ctypes.data)                                               # noqa: E731

@@ -529,9 +529,8 @@ def test_reduced_mode_table_and_loop_paths_agree_sample_by_sample(pem, oc):
 @pytest.mark.parametrize('R', [2, 3, 4, 5, 6, 7, 8, 9, 13, 16, 17, 25, 31, 32, 33, 47, 64, 65, 70, 256, 257])
 def test_sweep_radius_counts_across_the_kernel_switches(pem, oc, R):
     """sweep_radius arrays: the recurrence kernel for 2..8 radii (register blocks of 2 / 4 / 8 radii, 8- and 16-byte stores),
-    the staged kernel for 9..64 (four / two / one samples in flight per wave: switches at 16 and 32; odd counts start every
-    second sample's runs on an odd double), the wave-per-sample kernel for 65..256 (whose radius loop runs in chunks of 64
-    lanes), the lane-per-sample kernel above -- every count at a switch against the oracle, invalid samples included, also
+    the wave-per-sample kernel for 9..16 and 65..256 (whose radius loop runs in chunks of 64 lanes), the staged kernel for
+    17..64 (two / one samples in flight per wave: switch at 32; odd counts start every second sample's runs on an odd double), the lane-per-sample kernel above -- every count at a switch against the oracle, invalid samples included, also
     with a ragged tile (n = 333)."""
     from hallthrusterpem_amd.models import current_density
     n = 333
