@@ -2,7 +2,7 @@
 """Differential fuzzing of the device path against the CPU oracle (test infrastructure) on inputs far outside the
 priors: signs, zeros, huge / tiny magnitudes, NaN / inf, beams around every table boundary.  For each seed the coupled
 evaluation runs in full, reduced and mixed mode, fused with the likelihood and with the SVD compression (against their
-two-launch pipelines), and the plume alone with one, two, three and five radii.
+two-launch pipelines), the tile-interleaved input layout, and the plume alone with one, two, three, five, nine, 17 and 40 radii.
 
 NaN / inf / invalid patterns must agree exactly.  Finite values are held to the north_star's 1e-10 relative, and where a
 result is a cancelling sum (negative amplitudes or densities, c0 outside [0, 1] -- none of which the priors reach) to
@@ -86,6 +86,7 @@ def main():
     ap.add_argument('--first-seed', type=int, default=0, help='first seed of the range (campaigns longer than one GPU call are run in pieces)')
     ap.add_argument('--seed-list', type=int, nargs='*', default=[], help='further seeds (e.g. the ones earlier campaigns failed on)')
     ap.add_argument('--n', type=int, default=20_000)
+    ap.add_argument('--many-radii-samples', type=int, default=3000, help='samples per seed that also go through 9 / 17 / 40 sweep radii')
     ap.add_argument('--dump', default='', help='write the worst sample of every quantity (inputs, got, want) to this .npz')
     ap.add_argument('--priors', type=int, default=0, metavar='BATCHES',
                     help='instead: BATCHES x 1.25e6 samples drawn from the PEM-v0 priors, full and reduced mode, strict 1e-10')
@@ -169,6 +170,14 @@ def main():
                 else:
                     note(f'{name}.{key}', rel_err(g, w))
             plume_check(name, got, want, bounds, seed, with_j=(name == 'full'), inputs={**x, 'I_B0': want['I_B0']})
+        # the tile-interleaved input layout (pem_coupled_tiled_f64_dev) is the same evaluation bit for bit, wild inputs included
+        tb = CoupledBatch(args.n, layout='tile')
+        tb.set_inputs(x)
+        tb.run()
+        torch.cuda.synchronize()
+        for key, val in tb.outputs().items():
+            assert np.array_equal(val.cpu().numpy().reshape(-1), np.asarray(full[key]).reshape(-1), equal_nan=True), f'tile layout differs: {key} (seed {seed})'
+        del tb
         b = CoupledBatch(args.n, mixed=True)
         b.set_inputs(x)
         b.run()
@@ -206,6 +215,18 @@ def main():
                 bR = pr.plume_bounds(tR, p['I_B0'])
             g = current_density(p, sweep_radius=radii[0] if len(radii) == 1 else np.array(radii))
             plume_check(f'plume[R={len(radii)}]', g, w, bR, seed, inputs=p)
+        # many radii, on the first samples of the seed (the blocks are large): 9 = the wave-per-sample kernel, 17 / 40 = the staged
+        # kernel with two / one samples in flight (odd and even counts: runs that start on odd and even doubles)
+        m = min(args.n, args.many_radii_samples)
+        ps = {q: np.ascontiguousarray(np.asarray(v)[:m]) for q, v in p.items()}
+        for R in (9, 17, 40):
+            radii = tuple(np.linspace(0.45, 2.6, R))
+            with np.errstate(all='ignore'):
+                w = oc.plume(ps['P_b'], ps['c0'], ps['c1'], ps['c2'], ps['c3'], ps['c4'], ps['c5'], ps['sigma_cex'], ps['I_B0'], k, T=ps['T'], radii=radii)
+                tR = oc.plume_terms(*[ps[q] for q in ('P_b', 'c0', 'c1', 'c2', 'c3', 'c4', 'c5', 'sigma_cex')], ps['I_B0'], k, radii=radii)
+                bR = pr.plume_bounds(tR, ps['I_B0'])
+            g = current_density(ps, sweep_radius=np.array(radii))
+            plume_check(f'plume[R={R}]', g, w, bR, seed, inputs=ps)
     print(f'{len(seeds)} seeds x {args.n} wild samples (seeds {args.first_seed}..{args.seeds - 1}' + (f' + {args.seed_list}' if args.seed_list else '') + '):')
     print('NaN / inf / invalid patterns identical everywhere; worst errors (1e-10 = at the bound) and the cancellation they met:')
     for key, v in sorted(worst.items()):
