@@ -617,6 +617,13 @@ void plume_r1_kernel(PlumeIO io, CoupledIO cio, long long ntiles, DesignArg<MC> 
         tab_simpson[i] = i < NANG ? make_double2(PEM_SIMPSON_CDEN[i], PEM_SIMPSON_CNUM[i]) : make_double2(0.0, 0.0);
     for (int i = tid; i < PEM_NDI * PEM_NDC; i += WAVE * WPB) tab_poly[i] = PEM_DPOLY[i];
     __syncthreads();   // the only workgroup barrier: from here on the waves are independent
+#if defined(PEM_STAGGER) && PEM_STAGGER > 0
+    // experiment: the first generation of workgroups starts in lock step (every wave in its prelude, then every wave storing);
+    // every other wave of it waits half a round before it begins
+    if (blockIdx.x < 512 && (wave & 1)) {
+        for (int i = 0; i < PEM_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
 
     const double rad = io.radius;
     const double inv_r2 = 1.0 / (rad * rad);
@@ -1239,14 +1246,9 @@ __global__ __launch_bounds__(WAVE * rfew_waves<R>()) void plume_rfew_kernel(Plum
                 const long long first = t * WAVE + (long long)round * RF_S;
                 long long valid = (io.n - first) * (long long)blk;          // doubles of this round that exist
                 if (valid > (long long)RF_S * (long long)blk) valid = (long long)RF_S * (long long)blk;
-                if (valid > 0) {
-                    double* out = io.j_ion + (size_t)first * blk;
-                    const int pieces = (int)(valid >> 1);
-                    const f64x2* src2 = reinterpret_cast<const f64x2*>(tile);
-                    f64x2* out2 = reinterpret_cast<f64x2*>(out);
-                    for (int i = lane; i < pieces; i += WAVE) stream_store(src2[i], &out2[i]);
-                    if ((valid & 1) && lane == 0) out[valid - 1] = tile[valid - 1];
-                }
+                // (for an odd R every other round starts 64 bytes into a 128-byte line: stream_run brings the body back onto
+                // line boundaries with one leading partial instruction)
+                if (valid > 0) stream_run(tile, io.j_ion + (size_t)first * blk, (int)valid, lane);
                 wave_lds_sync();   // the tile is rewritten by the next round
             }
         }

@@ -20,6 +20,7 @@ ap.add_argument('--rounds', type=int, default=6)
 ap.add_argument('--reps', type=int, default=10)
 ap.add_argument('--layout', default='soa')
 ap.add_argument('--streams', default='1,2')
+ap.add_argument('--libs', default='', help='name=path,... : variant libraries (tools/build_variant.sh); a mode "lib:name" launches through one')
 args = ap.parse_args()
 N = 1_250_000
 batches = []
@@ -36,11 +37,28 @@ res = {(m, s): [] for m in modes for s in NS}
 KEYS = ('PEM_GRID_MULT', 'PEM_WAVES_PER_CU')
 
 
+import ctypes as C                                         # noqa: E402
+from hallthrusterpem_amd import _lib as L                  # noqa: E402
+main_lib = L.load()
+variants = {}
+for spec in filter(None, args.libs.split(',')):
+    name, path = spec.split('=')
+    h = C.CDLL(str(Path(path).resolve()))
+    for fn, (res, argt) in L.SIGNATURES.items():
+        getattr(h, fn).restype = res
+        getattr(h, fn).argtypes = argt
+    variants[name] = h
+
+
 def set_mode(m):
     for k in KEYS:
         os.environ.pop(k, None)
+    L._lib = main_lib
     if m != 'default':
         for kv in m.split('+'):
+            if kv.startswith('lib:'):
+                L._lib = variants[kv[4:]]
+                continue
             k, v = kv.split('=')
             os.environ[k] = v
 
