@@ -617,13 +617,6 @@ void plume_r1_kernel(PlumeIO io, CoupledIO cio, long long ntiles, DesignArg<MC> 
         tab_simpson[i] = i < NANG ? make_double2(PEM_SIMPSON_CDEN[i], PEM_SIMPSON_CNUM[i]) : make_double2(0.0, 0.0);
     for (int i = tid; i < PEM_NDI * PEM_NDC; i += WAVE * WPB) tab_poly[i] = PEM_DPOLY[i];
     __syncthreads();   // the only workgroup barrier: from here on the waves are independent
-#if defined(PEM_STAGGER) && PEM_STAGGER > 0
-    // experiment: the first generation of workgroups starts in lock step (every wave in its prelude, then every wave storing);
-    // every other wave of it waits half a round before it begins
-    if (blockIdx.x < 512 && (wave & 1)) {
-        for (int i = 0; i < PEM_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
 
     const double rad = io.radius;
     const double inv_r2 = 1.0 / (rad * rad);

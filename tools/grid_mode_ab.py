@@ -44,9 +44,9 @@ variants = {}
 for spec in filter(None, args.libs.split(',')):
     name, path = spec.split('=')
     h = C.CDLL(str(Path(path).resolve()))
-    for fn, (res, argt) in L.SIGNATURES.items():
-        getattr(h, fn).restype = res
-        getattr(h, fn).argtypes = argt
+    for fn, (restype_, argtypes_) in L.SIGNATURES.items():
+        getattr(h, fn).restype = restype_
+        getattr(h, fn).argtypes = argtypes_
     variants[name] = h
 
 
