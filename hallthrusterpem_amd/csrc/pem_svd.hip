@@ -417,6 +417,15 @@ int check_args(const char* who, size_t n, int dof, int r, int mode, const void* 
 // -- where that keeps >= 90 % of the slots in use (with two or three rounds the missing parallelism costs more).
 size_t balanced_blocks(size_t need, size_t cap) {
     if (need <= cap) return need;
+    if (const char* e = getenv("PEM_SVD_GRID_MULT")) {     // experiments: m x the resident slots (0: one tile per wave)
+        const long long m = atoll(e);
+        return (m <= 0 || (size_t)m * cap > need) ? need : (size_t)m * cap;
+    }
+    // more than three rounds of work: four times the resident workgroups, dealt out by the dispatcher as slots free up -- the
+    // static walk ends with the slowest wave (pem_kernels.hip persistent_grid); one tile per wave would pay the tables and the
+    // register-resident basis once per tile.  1.25e6 profiles, streaming: compress with log10 268 -> 255 us, reconstruct
+    // without a norm 183 -> 174 us, the other two unchanged (profiles/svd_grid_r03.txt)
+    if (need > 3 * cap) return need < 4 * cap ? need : 4 * cap;
     const size_t rounds = (need + cap - 1) / cap;
     const size_t g = (need + rounds - 1) / rounds;
     return 10 * g >= 9 * cap ? g : cap;
