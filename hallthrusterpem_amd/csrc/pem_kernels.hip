@@ -1545,7 +1545,7 @@ int launch_rfew(size_t n, hipStream_t st, const PlumeIO& io, const RadiiSmallArg
     HIP_TRY(pem::device_cus(&cus));
     const size_t per_cu = (160 * 1024) / lds < 2 ? 1 : 2;          // persistent: workgroups resident per CU
     size_t grid = ((n + WAVE - 1) / WAVE + NW - 1) / NW;
-    grid = balanced_grid(grid, (size_t)cus * per_cu);
+    grid = balanced_grid(grid, (size_t)cus * per_cu);     // (grids of 2 / 4 x the slots or one tile per wave: within 2 %, r03o)
     hipLaunchKernelGGL(plume_rfew_kernel<R>, dim3((unsigned)grid), dim3(WAVE * NW), lds, st, io, ra);
     HIP_TRY(hipGetLastError());
     return PEM_OK;
