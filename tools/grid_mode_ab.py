@@ -34,7 +34,7 @@ side = {1: [torch.cuda.current_stream()], 2: [torch.cuda.Stream(), torch.cuda.St
 NS = [int(v) for v in args.streams.split(',')]
 modes = args.modes.split(',')
 res = {(m, s): [] for m in modes for s in NS}
-KEYS = ('PEM_GRID_MULT', 'PEM_WAVES_PER_CU')
+KEYS = ('PEM_GRID_MULT', 'PEM_WAVES_PER_CU', 'PEM_TAIL_TILES')
 
 
 import ctypes as C                                         # noqa: E402
