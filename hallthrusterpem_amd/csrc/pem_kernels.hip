@@ -856,9 +856,10 @@ __global__ __launch_bounds__(BLOCK) void plume_radii_kernel(PlumeIO io, RadiiArg
 // ---------------------------------------------------------------------------------------------
 // sweep_radius arrays, RADII_SMALL < R <= RMID_MAX (tests/test_plume.py:31 uses 25): the recipe of the few-radii kernel below
 // applied to the wave-per-sample kernel above -- several samples in flight per wave, the block staged in LDS in final order,
-// 16-byte stores of whole contiguous runs.  G = 4 / 2 / 1 samples share a wave (R <= 16 / 32 / 64): lane (grp, r) owns radius
-// r of sample grp, keeps its amplitudes in registers and walks the 91 angles; the two Gaussians of a sample (91 direct exp()
-// each: the reference's literal expression, deep tail included) are read from LDS as one broadcast 16-byte word per angle.
+// 16-byte stores of whole contiguous runs.  G = 64 / R samples share a wave (7 at 9 radii ... 1 above 32): lane (grp, r) owns radius
+// r of sample grp, keeps its amplitudes in registers and walks the 91 angles; the two Gaussians of a sample (by recurrence from
+// three exp per beam and lane, literal exp() where the reference's own has left the normal range) are read from LDS as one
+// broadcast 16-byte word per angle.
 // What the lane produces -- b1[r] e1[k] + b2[r] e2[k] + j_cex[r], the Simpson sums of plume.py:117-123 taken angle by angle as the
 // reference takes them -- goes to an LDS tile laid out as j_ion is, `kc` rows of every sample at a time (8 KB per wave), and
 // leaves as runs of kc R contiguous doubles: one leading 8-byte store where a run starts on an odd double (the LDS copy is
@@ -881,13 +882,16 @@ __device__ __forceinline__ void stream_run(const double* from, double* dst, int 
     if (((len - head) & 1) && lane == 0) __builtin_nontemporal_store(from[len - 1], dst + (len - 1));
 }
 
+constexpr int RADII_SMALL = 8;                  // up to here: the recurrence kernel with the radii in registers (plume_rfew_kernel)
 constexpr int RMID_MAX = 64;
 constexpr int RMID_TILE = 1024;                 // doubles of staged rows per wave
 struct RadiiMidArg {
     double r[RMID_MAX];
 };
+constexpr int RMID_ES = 97;                     // 16-byte words of E per sample: an odd stride, so that the G broadcast reads of an
+                                                // instruction fall on different banks (96: all on the same ones, G-way conflict)
 template <int G>
-constexpr int rmid_wave_doubles() { return G * 96 * 2 + RMID_TILE + 2; }
+constexpr int rmid_wave_doubles() { return ((G * RMID_ES * 2 + 1) & ~1) + RMID_TILE + 2; }
 
 #ifndef PEM_RMID_WAVES
 #define PEM_RMID_WAVES 3
@@ -896,18 +900,19 @@ template <int G>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(PEM_RMID_WAVES)))
 void plume_rmid_kernel(PlumeIO io, RadiiMidArg radii_arg, int R, int ts) {
 #pragma clang fp contract(off)
-    constexpr int LS = WAVE / G;                // lanes per sample
-    constexpr int RS = RMID_TILE / G;           // doubles of the tile per sample (even)
+    const int LS = R;                           // lanes per sample: exactly its radii (G = 64 / R samples share the wave)
+    constexpr int RS = (RMID_TILE / G) & ~1;    // doubles of the tile per sample (even)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double* mine = reinterpret_cast<double*>(smem_raw) + (size_t)wave * rmid_wave_doubles<G>();
-    double2* E = reinterpret_cast<double2*>(mine);   // [G][96] {e1[k], e2[k]}
-    double* tile = mine + G * 96 * 2;                 // [G][RS] staged rows (16-byte aligned)
-    const int grp = lane / LS, r = lane - grp * LS;
-    const bool lane_on = r < R;
+    double2* E = reinterpret_cast<double2*>(mine);   // [G][RMID_ES] {e1[k], e2[k]}
+    double* tile = mine + ((G * RMID_ES * 2 + 1) & ~1);   // [G][RS] staged rows (16-byte aligned)
+    const int grp_raw = lane / LS, r = lane - grp_raw * LS;
+    const bool lane_on = grp_raw < G;                 // the lanes past G R idle (they still take part in every shuffle)
+    const int grp = lane_on ? grp_raw : G - 1;
     const int kc = (RS - 2) / R;                      // rows per chunk: kc R + 1 <= RS - 1
     const double rad = radii_arg.r[r];
-    const unsigned long long group_mask = (LS == 64 ? ~0ull : ((1ull << LS) - 1)) << (grp * LS);
+    const unsigned long long group_mask = (LS == 64 ? ~0ull : ((1ull << LS) - 1)) << (grp * LS);   // (R = 64 only with G = 1)
     const long long nwaves = (long long)gridDim.x * (BLOCK / WAVE);
     const bool have_T = io.T != nullptr;
     const long long ntiles = (io.n + ts - 1) / ts;
@@ -924,17 +929,46 @@ void plume_rmid_kernel(PlumeIO io, RadiiMidArg radii_arg, int R, int ts) {
         const double thrust_l = have_T ? io.T[gl] : 0.0;
         const int in_tile = (int)(io.n - t * ts < ts ? io.n - t * ts : ts);
         for (int s0 = 0; s0 < in_tile; s0 += G) {
-            // the Gaussians of the group's samples: G x 91 items over the wave (every lane takes part in every shuffle)
+            // The Gaussians of the group's samples: the LS lanes of a sample take CHK consecutive angles each and advance
+            // e_k = exp(-(k h / a)^2) by the two-term recurrence of the R = 1 kernel (e_{k+1} = e_k r_k, r_{k+1} = r_k q) from
+            // three branch-free exp per beam -- 6 instead of 2 CHK library exp() per lane (364 per group at G = 4).  A chunk in
+            // which the reference's own exp() has left the normal range (a value below 1e-290), or whose widths are not finite
+            // numbers, is evaluated literally as the reference does (plume.py:99-100), deep tail included.
+            {
+                // G = 64 / R samples per wave  =>  R > 64 / (G + 1): the longest chunk a lane can get (R >= 9 always: 11 angles)
+                constexpr int R_MIN = (WAVE / (G + 1) + 1) > RADII_SMALL + 1 ? (WAVE / (G + 1) + 1) : RADII_SMALL + 1;
+                constexpr int CHK_MAX = (NANG + R_MIN - 1) / R_MIN;
+                const int chk = (NANG + LS - 1) / LS;
+                const int k0 = r * chk;
+                const int sm = s0 + grp < in_tile ? s0 + grp : in_tile - 1;
+                const double a1g = __shfl(a1_l, sm), a2g = __shfl(a2_l, sm);
+                const double s1 = (GRID_H * GRID_H) * (1.0 / (a1g * a1g)), s2 = (GRID_H * GRID_H) * (1.0 / (a2g * a2g));
+                double e1 = exp_nonpos(-(double)(k0 * k0) * s1), r1 = exp_nonpos(-(double)(2 * k0 + 1) * s1);
+                double e2 = exp_nonpos(-(double)(k0 * k0) * s2), r2 = exp_nonpos(-(double)(2 * k0 + 1) * s2);
+                const double q1 = exp_nonpos(-2.0 * s1), q2 = exp_nonpos(-2.0 * s2);
+                double2 ev[CHK_MAX];
+                double lo = __builtin_inf();
 #pragma unroll
-            for (int it = 0; it < (G * NANG + WAVE - 1) / WAVE; ++it) {
-                const int item = it * WAVE + lane;
-                const bool valid = item < G * NANG;
-                const int gi = valid ? item / NANG : 0, k = valid ? item - gi * NANG : 0;
-                const int sm = s0 + gi < in_tile ? s0 + gi : in_tile - 1;
-                const double a1 = __shfl(a1_l, sm), a2 = __shfl(a2_l, sm);
-                const double alpha = k == NANG - 1 ? HALF_PI : (double)k * GRID_H;
-                const double t1 = alpha / a1, t2 = alpha / a2;
-                if (valid) E[gi * 96 + k] = make_double2(exp(-(t1 * t1)), exp(-(t2 * t2)));
+                for (int i = 0; i < CHK_MAX; ++i) {
+                    ev[i] = make_double2(e1, e2);
+                    if (i < chk) lo = fmin(lo, fmin(e1, e2));
+                    e1 *= r1;
+                    r1 *= q1;
+                    e2 *= r2;
+                    r2 *= q2;
+                }
+                if (!(lo >= 1e-290) || !__builtin_isfinite(s1) || !__builtin_isfinite(s2)) {
+#pragma unroll
+                    for (int i = 0; i < CHK_MAX; ++i) {
+                        const int k = k0 + i;
+                        const double alpha = k >= NANG - 1 ? HALF_PI : (double)k * GRID_H;
+                        const double t1 = alpha / a1g, t2 = alpha / a2g;
+                        if (i < chk) ev[i] = make_double2(exp(-(t1 * t1)), exp(-(t2 * t2)));
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < CHK_MAX; ++i)
+                    if (i < chk && lane_on && k0 + i < NANG) E[grp * RMID_ES + k0 + i] = ev[i];
             }
             // this lane's (sample, radius): amplitudes of plume.py:95-100
             const bool smp_on = s0 + grp < in_tile;
@@ -960,7 +994,7 @@ void plume_rmid_kernel(PlumeIO io, RadiiMidArg radii_arg, int R, int ts) {
 #pragma unroll 4
                         for (int kk = 0; kk < rows; ++kk) {
                             const int k = k0 + kk;
-                            const double2 ee = E[grp * 96 + k];
+                            const double2 ee = E[grp * RMID_ES + k];
                             const double f = b1 * ee.x + b2 * ee.y;      // j_beam + j_scat
                             const double ji = f + j_cex;                  // plume.py:102
                             run[kk * R + r] = ji;
@@ -997,7 +1031,6 @@ void plume_rmid_kernel(PlumeIO io, RadiiMidArg radii_arg, int R, int ts) {
     }
 }
 
-constexpr int RADII_SMALL = 8;
 struct RadiiSmallArg {
     double r[RADII_SMALL];
 };
@@ -1823,15 +1856,22 @@ int pem_plume_f64_dev(size_t n, int n_radii, const double* radii, double torr2pa
         return PEM_OK;
     }
     static const bool use_rmid = getenv("PEM_RADII_MID") ? atoi(getenv("PEM_RADII_MID")) != 0 : true;
-    if (use_rmid && n_radii > 16 && n_radii <= RMID_MAX) {
-        // two / one samples in flight per wave, rows staged in LDS, line-aligned 16-byte stores (plume_rmid_kernel): 3.4-5.2 TB/s
-        // of output for 17..64 radii against 3.3-4.9 for the wave-per-sample kernel below (25 radii: 3.8-4.0 against 3.2-3.35);
-        // with four samples in flight (9..16 radii) the 364 direct exp() per group weigh more than the staging saves (2.6-3.7
-        // against 2.9-3.9), so those counts stay with the kernel below (profiles/radii_mid_r03.txt)
+    static const int rmid_min = getenv("PEM_RMID_MIN") ? atoi(getenv("PEM_RMID_MIN")) : 17;
+    if (use_rmid && n_radii >= rmid_min && n_radii > RADII_SMALL && n_radii <= RMID_MAX) {
+        // 64 / R samples in flight per wave, rows staged in LDS, line-aligned 16-byte stores (plume_rmid_kernel): 3.5-5.2 TB/s
+        // of output for 17..64 radii against 3.3-4.9 for the wave-per-sample kernel below (25 radii: 3.8-4.0 against 3.2-3.35).
+        // From 9 radii on (PEM_RMID_MIN=9) it works but gains nothing over the kernel below (2.9 / 3.3 / 3.9 against 2.9 / 3.1 /
+        // 4.1 TB/s at 9 / 12 / 16 radii): seven samples share the 8 KB of staged rows, and their 1.1 KB runs pay the run's head /
+        // body / tail code 42 times per group (profiles/radii_mid_r03.txt)
         RadiiMidArg ra;
         for (int r = 0; r < RMID_MAX; ++r) ra.r[r] = r < n_radii ? radii[r] : 1.0;
         int ts = WAVE;                             // samples per wave tile: fewer when the batch is small
         while (ts > 8 && (n + ts - 1) / ts < 256 * 32) ts >>= 1;
+        {   // whole groups only: G = 64 / R samples are in flight at a time, a tile of 8 would leave a second group of one
+            const int G = WAVE / n_radii;
+            ts = ts / G * G;
+            if (ts < 2 * G) ts = 2 * G <= WAVE ? 2 * G : G;
+        }
         if (const char* e = getenv("PEM_RMID_TS")) ts = atoi(e);                      // experiments
         const size_t ntiles = (n + ts - 1) / ts;
         int cus = 256;
@@ -1845,9 +1885,15 @@ int pem_plume_f64_dev(size_t n, int n_radii, const double* radii, double torr2pa
         blocks = balanced_grid(blocks, (size_t)cus * per_cu);                                                       \
         hipLaunchKernelGGL(plume_rmid_kernel<G_>, dim3((unsigned)blocks), dim3(BLOCK), lds, st, io, ra, n_radii, ts); \
     } while (0)
-        if (n_radii <= 16) PEM_RMID_LAUNCH(4);
-        else if (n_radii <= 32) PEM_RMID_LAUNCH(2);
-        else PEM_RMID_LAUNCH(1);
+        switch (WAVE / n_radii) {          // samples in flight per wave
+            case 1: PEM_RMID_LAUNCH(1); break;
+            case 2: PEM_RMID_LAUNCH(2); break;
+            case 3: PEM_RMID_LAUNCH(3); break;
+            case 4: PEM_RMID_LAUNCH(4); break;
+            case 5: PEM_RMID_LAUNCH(5); break;
+            case 6: PEM_RMID_LAUNCH(6); break;
+            default: PEM_RMID_LAUNCH(7); break;
+        }
 #undef PEM_RMID_LAUNCH
         HIP_TRY(hipGetLastError());
         return PEM_OK;
