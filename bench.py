@@ -507,6 +507,11 @@ def main():
                                             f'launch size, gfx950 corrections applied; same kernel sources, kernel_srchash {kernel_source_hash()}); '
                                             f'not measured in this run') if traffic else f'none: {traffic_why}',
                          'kernel': 'plume_r1_kernel<L,COUPLED,JMODE>', 'kernel_ms_mean': kern_mean_ms,
+                         'kernel_ms_note': ('ISOLATED launches, one at a time on one stream, HIP events around each (what rocprofv3 --kernel-trace '
+                                            'reports for `bench.py --streams 1`: profiles/r03s1_summary.md).  With --streams 2 consecutive launches '
+                                            'overlap at their ends: ms_per_step is then SMALLER than this, and per-dispatch durations in a trace of '
+                                            'that command are longer than a step (profiles/r03s2_raw/)') if side is not None else
+                                           'launches one at a time on one stream, HIP events around each',
                          'kernel_ms_min': kern_min_ms, 'bytes_per_eval': batch.bytes_per_eval,
                          'bytes_per_launch': bytes_per_launch,
                          'steps_overlapped': ({'streams': args.streams, 'ms_per_step': 1e3 * elapsed / args.steps,
