@@ -5,19 +5,17 @@ from pathlib import Path
 
 import yaml
 
+_PARSERS = {'.yml': yaml.safe_load, '.json': json.load}
 
-def _first_reference(node, value):
-    """(dict, key) of the first entry equal to `value`, visiting nested DICTS in key order, depth first -- what the reference's
-    `_path_in_dict` finds (src/hallmd/utils.py:12-21).  Lists are not searched: the reference never looks inside one."""
-    if isinstance(node, dict):
-        for key, child in node.items():
-            if isinstance(child, dict):
-                hit = _first_reference(child, value)
-                if hit is not None:
-                    return hit
-            elif child == value:
-                return node, key
-    return None
+
+def _mentions(tree: dict, wanted: str):
+    """Every (holder, key) with holder[key] == wanted, nested DICTS visited in key order, depth first; lists are leaves that
+    never match -- the order in which the reference's `_path_in_dict` (src/hallmd/utils.py:12-21) would meet them."""
+    for key, child in tree.items():
+        if isinstance(child, dict):
+            yield from _mentions(child, wanted)
+        elif child == wanted:
+            yield tree, key
 
 
 def load_thruster(thruster_dir: str | Path, thruster_filename: str = 'thruster.yml') -> dict:
@@ -32,18 +30,14 @@ def load_thruster(thruster_dir: str | Path, thruster_filename: str = 'thruster.y
     top-level dict at every key (`d = config[key]`, utils.py:82) and ends in a KeyError there."""
     root = Path(thruster_dir)
     spec = root / thruster_filename
-    with open(spec, 'r', encoding='utf-8') as fd:
-        if spec.suffix == '.yml':
-            device = yaml.safe_load(fd)
-        elif spec.suffix == '.json':
-            device = json.load(fd)
-        else:
-            raise ValueError(f'Unsupported file type "{spec.suffix}". Only .yml and .json files are supported.')
-    for folder, _, names in os.walk(root):
-        for name in names:
-            path = Path(folder) / name
-            hit = _first_reference(device, path.relative_to(root).as_posix()) or _first_reference(device, name)
-            if hit is not None:
-                holder, key = hit
-                holder[key] = path.resolve().as_posix()
+    parse = _PARSERS.get(spec.suffix)
+    if parse is None:
+        raise ValueError(f'Unsupported file type "{spec.suffix}". Only .yml and .json files are supported.')
+    device = parse(spec.read_text(encoding='utf-8')) if parse is yaml.safe_load else json.loads(spec.read_text(encoding='utf-8'))
+    # the files in the order the reference meets them (os.walk): it matters when two of them compete for one mention
+    present = [Path(folder, name) for folder, _, names in os.walk(root) for name in names]
+    for found in present:
+        hit = next(_mentions(device, found.relative_to(root).as_posix()), None) or next(_mentions(device, found.name), None)
+        if hit:
+            hit[0][hit[1]] = found.resolve().as_posix()
     return device
