@@ -117,15 +117,17 @@ def discard_mask(nan_idx: dict, outlier_idx: dict, discard_outliers: bool = Fals
 
 # ------------------------------------------------------------------------------------------- forward evaluation loops
 def forward_uq(n: int, seed: int = 0, method: str = 'mc', profile: bool = False, batch_size: int = 1 << 21,
-               priors=None, device=None, keep_profile: bool = False, rank: int = 0, world: int = 1, streams: int = 2):
+               priors=None, device=None, keep_profile: bool = False, rank: int = 0, world: int = 1, streams: int = 1):
     """Forward propagation of the PEM-v0 priors through cathode -> thruster (test double) -> plume.
 
     Draws global samples [0, n) of the counter-based design (this rank evaluates its contiguous shard), evaluates
     them in batches of `batch_size` and returns per-sample QoIs of the shard as CUDA tensors:
     `V_cc, div_angle, T_c, I_B0, T, invalid`, the inputs `x` ([15][n_local]) and, if `keep_profile`, `j_ion`.
-    A shard of several batches deals its launches onto `streams` side streams (they write disjoint ranges): launch i+1 then
-    starts on the wave slots the tail of launch i leaves idle (3-7 % per launch with the profile written,
-    profiles/grid_modes_r03.txt); the side streams begin after, and the caller's stream continues after, everything enqueued here."""
+    `streams` > 1 deals the launches of a shard of several batches onto that many side streams (they write disjoint ranges; the side
+    streams begin after, and the caller's stream continues after, everything enqueued here).  It is NOT the default: what gains
+    3-7 % for the evaluate-only launches of bench.py loses 8-20 % here (1e7 samples: 1.77 -> 1.92 ms with the profile, 0.71 -> 0.86 ms
+    without) -- the fused Monte-Carlo launches are persistent grids sized to fill the chip, and two of them dispatched side by side
+    each run as two passes (tools/forward_uq_streams_probe.py, profiles/launch_amortisation_r03.txt)."""
     import torch
     design = sampling.Design(priors=priors, seed=seed)
     lo, hi = shard_bounds(n, world, rank)
