@@ -50,11 +50,14 @@ def chunk_bounds(n: int, chunks: int, align: int = 64, round_samples: int | None
     (whole 64-sample kernel tiles; 16-byte aligned profile rows).  Returns [(first, count), ...]; none is empty.
 
     `round_samples`: the samples ONE round of the persistent evaluation kernel covers (`launch_rounds`; resident waves x 64).
-    A range launch costs whole rounds -- a tile's duration is latency, so a round that is 38 % full takes as long as a full
-    one (tools/tail_probe.py) -- so with it every piece but the last is a whole number of rounds and the shard's own ragged
-    tail is the only partly filled round of the step, exactly as in the single launch.  The rounds are dealt out as evenly
-    as they divide, the longer pieces first (the last piece, which also carries the tail, is never the longest).  Without
-    it the pieces differ by at most `align` samples (the cut used when nothing is known about the kernel: CPU rehearsals)."""
+    With it every piece but the last is a whole number of rounds and the shard's own ragged tail is the only partly filled
+    round of the step; the rounds are dealt out as evenly as they divide, the longer pieces first.  This is the cut VERDICT r2
+    asked for on the premise that a partly filled round costs a whole one.  Measured through the 1-rank RCCL path at the full
+    1.25e6-sample shard (profiles/schedule_r03.txt) it is SLOWER than equal pieces on one stream (5.4-5.5e9 against 5.8e9
+    evaluations/s at K = 4) and equal on two: a short launch's time follows its bytes (2.38 rounds: 54 us, between the 46 us of
+    two rounds and the 71 us of three), and a 312 512-sample piece's 227 MB of output still fit the 256 MB Infinity Cache.
+    Equal pieces (round_samples=None: they differ by at most `align` samples) are therefore what `ChunkedGather` and
+    bench.py use by default; the round-aligned cut stays available (`bench.py --chunk-align round`)."""
     if n <= 0:
         return []
     if round_samples:
