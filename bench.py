@@ -240,11 +240,13 @@ def main():
                                                           'overlaps the evaluation of piece k+1')
     ap.add_argument('--layout', choices=['soa', 'tile'], default='tile',
                     help="input layout: soa = 15 arrays (pem_coupled_f64_dev); tile = [tiles][15][64] blocks (pem_coupled_tiled_f64_dev)")
-    ap.add_argument('--streams', type=int, default=2, choices=[1, 2, 4],
+    ap.add_argument('--streams', type=int, default=None, choices=[1, 2, 4],
                     help='consecutive launches (steps; at N > 1 the chunk launches of the pipeline) are dealt onto this many HIP '
                          'streams, so that launch i+1 fills the wave slots the tail of launch i leaves idle; 1 = every launch waits for '
-                         'the one before (rounds 1-2).  The roofline object always quotes the duration of ISOLATED launches; the '
-                         'one-stream rate of the same run is carried as config.single_stream')
+                         'the one before (rounds 1-2).  Default: 2 when the profile is written, 1 with --no-profile (the reduced-QoI '
+                         'kernel is VALU-bound and two of its launches side by side take twice as long each: '
+                         'profiles/launch_amortisation_r03.txt).  The roofline object always quotes the duration of ISOLATED '
+                         'launches; the one-stream rate of the same run is carried as config.single_stream')
     ap.add_argument('--no-single-batch', action='store_true', help='skip the cache-assisted single-batch comparison run (profiling: every launch is then a rotating one)')
     ap.add_argument('--no-profile', action='store_true', help='reduced-QoI mode: never write j_ion (144 B/eval)')
     ap.add_argument('--mixed', action='store_true', help='fp64 arithmetic, fp32 storage of the profile (508 B/eval)')
@@ -308,6 +310,8 @@ def main():
     _lib.require_device()
     if args.mixed:
         args.layout = 'soa'                      # the fp32-profile entry point takes the 15 arrays only
+    if args.streams is None:
+        args.streams = 1 if args.no_profile else 2
     lanes = lib.pem_set_lanes_per_sample(args.lanes)
     n = args.samples_per_gpu
     # outputs per evaluation exactly as SURVEY section 8d counts them: V_cc, j_ion[91], div_angle, T_c (+ invalid flag)
