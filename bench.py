@@ -243,7 +243,7 @@ def main():
     ap.add_argument('--streams', type=int, default=None, choices=[1, 2, 4],
                     help='consecutive launches (steps; at N > 1 the chunk launches of the pipeline) are dealt onto this many HIP '
                          'streams, so that launch i+1 fills the wave slots the tail of launch i leaves idle; 1 = every launch waits for '
-                         'the one before (rounds 1-2).  Default: 2 when the profile is written, 1 with --no-profile (the reduced-QoI '
+                         'the one before (rounds 1-2).  Default: 2 when the fp64 profile is written (the benchmark), 1 with --no-profile / --mixed (the reduced-QoI '
                          'kernel is VALU-bound and two of its launches side by side take twice as long each: '
                          'profiles/launch_amortisation_r03.txt).  The roofline object always quotes the duration of ISOLATED '
                          'launches; the one-stream rate of the same run is carried as config.single_stream')
@@ -311,7 +311,7 @@ def main():
     if args.mixed:
         args.layout = 'soa'                      # the fp32-profile entry point takes the 15 arrays only
     if args.streams is None:
-        args.streams = 1 if args.no_profile else 2
+        args.streams = 1 if (args.no_profile or args.mixed) else 2
     lanes = lib.pem_set_lanes_per_sample(args.lanes)
     n = args.samples_per_gpu
     # outputs per evaluation exactly as SURVEY section 8d counts them: V_cc, j_ion[91], div_angle, T_c (+ invalid flag)
