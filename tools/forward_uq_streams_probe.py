@@ -1,3 +1,4 @@
+"""drivers.forward_uq (fused Monte-Carlo launches of 2^21 samples) with its launches on one stream or dealt onto two: wall time per\ncampaign of 1e7 / 5e6 samples, with and without the profile (profiles/launch_amortisation_r03.txt)."""
 import sys, time, torch
 sys.path.insert(0, '/root/repo')
 from hallthrusterpem_amd import drivers
