@@ -161,11 +161,25 @@ def forward_uq(n: int, seed: int = 0, method: str = 'mc', profile: bool = False,
     return out
 
 
-def percentile_bands(outputs: dict, percentiles=(5.0, 50.0, 95.0), names=('V_cc', 'div_angle', 'T_c', 'j_ion')):
+def percentile_bands(outputs: dict, percentiles=(5.0, 50.0, 95.0), names=('V_cc', 'div_angle', 'T_c', 'j_ion'), group=None,
+                     sharded: bool | None = None):
     """The 5 / 50 / 95 % bands monte_carlo.py:363-658 draws from its prior / posterior predictive samples
     (`np.percentile(ys, x, axis=0)`), for the device-resident outputs of `forward_uq`: {name: (len(percentiles), ...) CUDA
-    tensor}, equal to numpy's values bit for bit (`column_percentiles`).  Samples flagged `invalid` are kept, as there."""
-    return {k: column_percentiles(outputs[k], list(percentiles)) for k in names if k in outputs}
+    tensor}, equal to numpy's values bit for bit (`column_percentiles`).  Samples flagged `invalid` are kept, as there.
+
+    sharded (default: whenever a process group of more than one rank is initialised): `outputs` is THIS rank's shard of the
+    campaign (`forward_uq(..., rank=, world=)`) and the bands are those of ALL ranks' samples, the same on every rank --
+    `percentiles.column_percentiles_sharded`: min / max and two histograms all-reduced, a few hundred candidates per wanted rank
+    all-gathered, nothing else crosses xGMI."""
+    import torch
+    if sharded is None:
+        import torch.distributed as dist
+        sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if not sharded:
+        return {k: column_percentiles(outputs[k], list(percentiles)) for k in names if k in outputs}
+    from .percentiles import column_percentiles_sharded
+    return {k: torch.from_numpy(np.ascontiguousarray(column_percentiles_sharded(outputs[k], list(percentiles), group=group))).to(outputs[k].device)
+            for k in names if k in outputs}
 
 
 def generate_data(system, description: str, num_samples: int = 500, executor=None, verbose: bool = False,

@@ -231,6 +231,10 @@ def _two_rank_worker(rank, world, port, out_dir):
         for k, pcts in (('j_ion', [5.0, 50.0, 95.0]), ('T_c', [25.0, 75.0])):
             got = column_percentiles_sharded(mine[k], pcts)
             assert np.array_equal(got, np.percentile(out[k].cpu().numpy(), pcts, axis=0), equal_nan=True), (rank, k)
+        # the driver-level form: the bands of the whole campaign from this rank's shard (sharded by default under a process group)
+        bands = drivers.percentile_bands(mine, names=('T_c', 'j_ion'))
+        for k in ('T_c', 'j_ion'):
+            assert bands[k].is_cuda and np.array_equal(bands[k].cpu().numpy(), np.percentile(out[k].cpu().numpy(), [5.0, 50.0, 95.0], axis=0), equal_nan=True)
         open(os.path.join(out_dir, f'ok{rank}'), 'w').write('ok')
     finally:
         dist.destroy_process_group()
