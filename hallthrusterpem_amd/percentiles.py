@@ -191,6 +191,13 @@ class NumpyColumns:
                 cand[c, t, :min(mine.size, list_len)] = mine[:list_len]
         return cand, cursor
 
+    # the two ways through a pass of up to three quantiles (`sharded_percentiles` calls these)
+    def select_pass(self, ranks, kmin, kmax, group):
+        return _numpy_pass(self, ranks, kmin, kmax, group)
+
+    def levels_pass(self, ranks, kmin, kmax, group):
+        return narrow_by_levels(lambda lo, hi, b: local_hist_numpy(self.a, lo, hi, b), ranks, kmin, kmax, group)
+
 
 def decide1(kmin, kmax, hist1, resid):
     """per (column, target): bin1 that holds the rank, the rank inside it; constant / empty columns are done (answer = kmin)"""
@@ -381,18 +388,6 @@ def sharded_percentiles(cols, percentiles, group=None, method: str = 'select'):
             out[qi] = lerp(vals[:, 2 * i], vals[:, 2 * i + 1], gamma[qi])
     out[:, (nan != 0) | empty] = np.nan
     return out[0] if scalar else out
-
-
-def _numpy_select_pass(self, ranks, kmin, kmax, group):
-    return _numpy_pass(self, ranks, kmin, kmax, group)
-
-
-def _numpy_levels_pass(self, ranks, kmin, kmax, group):
-    return narrow_by_levels(lambda lo, hi, b: local_hist_numpy(self.a, lo, hi, b), ranks, kmin, kmax, group)
-
-
-NumpyColumns.select_pass = _numpy_select_pass
-NumpyColumns.levels_pass = _numpy_levels_pass
 
 
 class DeviceColumns:
