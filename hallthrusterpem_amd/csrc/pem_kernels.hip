@@ -624,7 +624,22 @@ void plume_r1_kernel(PlumeIO io, CoupledIO cio, long long ntiles, DesignArg<MC> 
 
     // persistent loop over the tiles whose 64 samples all exist; inputs are prefetched one tile ahead
     const long long nfull = io.n / WAVE;
-    const long long me = (long long)blockIdx.x * WPB + wave, nwaves = (long long)gridDim.x * WPB;
+    // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one), so with tile = workgroup
+    // index every XCD writes every eighth 186-KB piece of j_ion; with the bijective remap below (cdna_hip_programming.md, "XCD
+    // swizzle must be bijective") the workgroups that share an XCD take one CONTIGUOUS eighth of the tiles, and each XCD's L2 hands
+    // the memory system one sequential stream instead of a comb.  There is no inter-workgroup reuse here -- the gain is in how the
+    // writes arrive at HBM: 202 -> 184 us per 1.25e6-sample launch, 183 -> 175 us per step on two streams (interleaved A/B,
+    // profiles/grid_modes_r03.txt).  Placement is a speed matter only: any assignment of tiles to workgroups is correct.
+#ifndef PEM_XCD_REMAP
+#define PEM_XCD_REMAP 1
+#endif
+#if PEM_XCD_REMAP
+    const unsigned xcd_q = gridDim.x >> 3, xcd_r = gridDim.x & 7, xcd = blockIdx.x & 7;
+    const long long vblock = (long long)(xcd < xcd_r ? xcd * (xcd_q + 1) : xcd_r * (xcd_q + 1) + (xcd - xcd_r) * xcd_q) + (blockIdx.x >> 3);
+#else
+    const long long vblock = blockIdx.x;
+#endif
+    const long long me = vblock * WPB + wave, nwaves = (long long)gridDim.x * WPB;
     long long t = me;
     if constexpr (MC) {
         for (; t < nfull; t += nwaves) {
