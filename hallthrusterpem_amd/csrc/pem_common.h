@@ -68,6 +68,26 @@ inline hipError_t device_cus(int* out) {
     return hipSuccess;
 }
 
+// XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one): with tile = workgroup index
+// every XCD touches every eighth piece of a streamed array; through this bijective remap (cdna_hip_programming.md: "XCD swizzle
+// must be bijective") the workgroups that share an XCD walk one contiguous eighth instead, and each XCD's L2 hands the memory
+// system one sequential stream.  A speed matter only: any assignment of tiles to workgroups is correct.  -DPEM_XCD_REMAP=0 turns
+// it off (A/B builds).  Used by plume_r1_kernel ONLY: measured on the other streaming kernels of the library (r03z) it costs --
+// SVD compress / reconstruct without a norm 191 -> 217 / 177 -> 199 us, the staged radii kernel 389 -> 500 us at 64 radii, the
+// likelihood kernel 172 -> 176 us: their workgroups walk several larger tiles each, and the contiguous eighths then put the 8
+// XCDs' frontiers 1/8 of the array apart instead of next to each other (profiles/grid_modes_r03.txt).
+#ifndef PEM_XCD_REMAP
+#define PEM_XCD_REMAP 1
+#endif
+__device__ __forceinline__ unsigned xcd_contiguous_block() {
+#if PEM_XCD_REMAP
+    const unsigned q = gridDim.x >> 3, r = gridDim.x & 7, x = blockIdx.x & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (blockIdx.x >> 3);
+#else
+    return blockIdx.x;
+#endif
+}
+
 }  // namespace pem
 
 #define HIP_TRY(expr)                                                                                   \

@@ -628,17 +628,9 @@ void plume_r1_kernel(PlumeIO io, CoupledIO cio, long long ntiles, DesignArg<MC> 
     // index every XCD writes every eighth 186-KB piece of j_ion; with the bijective remap below (cdna_hip_programming.md, "XCD
     // swizzle must be bijective") the workgroups that share an XCD take one CONTIGUOUS eighth of the tiles, and each XCD's L2 hands
     // the memory system one sequential stream instead of a comb.  There is no inter-workgroup reuse here -- the gain is in how the
-    // writes arrive at HBM: 202 -> 184 us per 1.25e6-sample launch, 183 -> 175 us per step on two streams (interleaved A/B,
-    // profiles/grid_modes_r03.txt).  Placement is a speed matter only: any assignment of tiles to workgroups is correct.
-#ifndef PEM_XCD_REMAP
-#define PEM_XCD_REMAP 1
-#endif
-#if PEM_XCD_REMAP
-    const unsigned xcd_q = gridDim.x >> 3, xcd_r = gridDim.x & 7, xcd = blockIdx.x & 7;
-    const long long vblock = (long long)(xcd < xcd_r ? xcd * (xcd_q + 1) : xcd_r * (xcd_q + 1) + (xcd - xcd_r) * xcd_q) + (blockIdx.x >> 3);
-#else
-    const long long vblock = blockIdx.x;
-#endif
+    // writes arrive at HBM: 210 -> 204 us per 1.25e6-sample launch, 204 -> 195 us per step on two streams (interleaved A/B,
+    // the same on four leases; a first box showed 202 -> 184: profiles/grid_modes_r03.txt).  The remap itself: pem_common.h.
+    const long long vblock = pem::xcd_contiguous_block();
     const long long me = vblock * WPB + wave, nwaves = (long long)gridDim.x * WPB;
     long long t = me;
     if constexpr (MC) {
@@ -772,7 +764,7 @@ __global__ __launch_bounds__(BLOCK) void plume_radii_kernel(PlumeIO io, RadiiArg
     // (coalesced input loads), and handed to the whole wave by shuffles as it walks through the blocks.  The host picks
     // ts = 64 for large batches and smaller tiles when there would otherwise be too few of them to fill the chip.
     const long long ntiles = (io.n + ts - 1) / ts;
-    for (long long t = blockIdx.x * (BLOCK / WAVE) + wave; t < ntiles; t += nwaves) {
+    for (long long t = (long long)blockIdx.x * (BLOCK / WAVE) + wave; t < ntiles; t += nwaves) {
     const long long gl = (lane < ts && t * ts + lane < io.n) ? t * ts + lane : io.n - 1;    // idle lanes repeat the last sample
     const double c0_l = io.c0[gl], c1_l = io.c1[gl];
     const PlumeSetup ps_l = plume_setup(io.P_b[gl], c1_l, io.c2[gl], io.c3[gl], io.c4[gl], io.c5[gl], io.torr2pa);
@@ -931,7 +923,7 @@ void plume_rmid_kernel(PlumeIO io, RadiiMidArg radii_arg, int R, int ts) {
     const long long nwaves = (long long)gridDim.x * (BLOCK / WAVE);
     const bool have_T = io.T != nullptr;
     const long long ntiles = (io.n + ts - 1) / ts;
-    for (long long t = blockIdx.x * (BLOCK / WAVE) + wave; t < ntiles; t += nwaves) {
+    for (long long t = (long long)blockIdx.x * (BLOCK / WAVE) + wave; t < ntiles; t += nwaves) {
         // parameters of the tile's samples, one lane per sample (as plume_radii_kernel)
         const long long gl = (lane < ts && t * ts + lane < io.n) ? t * ts + lane : io.n - 1;
         const double c0_l = io.c0[gl], c1_l = io.c1[gl];
