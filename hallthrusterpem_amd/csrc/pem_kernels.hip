@@ -630,7 +630,8 @@ void plume_r1_kernel(PlumeIO io, CoupledIO cio, long long ntiles, DesignArg<MC> 
     // the memory system one sequential stream instead of a comb.  There is no inter-workgroup reuse here -- the gain is in how the
     // writes arrive at HBM: 210 -> 204 us per 1.25e6-sample launch, 204 -> 195 us per step on two streams (interleaved A/B,
     // the same on four leases; a first box showed 202 -> 184: profiles/grid_modes_r03.txt).  The remap itself: pem_common.h.
-    const long long vblock = pem::xcd_contiguous_block();
+    // (the modes that write a profile; without one -- reduced QoIs, VALU-bound -- the remap measured 2 % slower: 48.4 against 47.2 us)
+    const long long vblock = (JMODE == 1 || JMODE == 2) ? (long long)pem::xcd_contiguous_block() : (long long)blockIdx.x;
     const long long me = vblock * WPB + wave, nwaves = (long long)gridDim.x * WPB;
     long long t = me;
     if constexpr (MC) {
