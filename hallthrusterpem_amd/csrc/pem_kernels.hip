@@ -630,8 +630,11 @@ void plume_r1_kernel(PlumeIO io, CoupledIO cio, long long ntiles, DesignArg<MC> 
     // the memory system one sequential stream instead of a comb.  There is no inter-workgroup reuse here -- the gain is in how the
     // writes arrive at HBM: 210 -> 204 us per 1.25e6-sample launch, 204 -> 195 us per step on two streams (interleaved A/B,
     // the same on four leases; a first box showed 202 -> 184: profiles/grid_modes_r03.txt).  The remap itself: pem_common.h.
-    // (the modes that write a profile; without one -- reduced QoIs, VALU-bound -- the remap measured 2 % slower: 48.4 against 47.2 us)
-    const long long vblock = (JMODE == 1 || JMODE == 2) ? (long long)pem::xcd_contiguous_block() : (long long)blockIdx.x;
+    // Where it pays: the modes that write a profile (without one -- reduced QoIs, VALU-bound -- it measured 2 % slower: 48.4 against
+    // 47.2 us), and one-shot grids only -- a persistent grid of a few rounds (312 512-sample pieces) ran at 249 against 215 us per
+    // 1.25e6 samples with it.
+    const bool one_tile_per_wave = (long long)gridDim.x * WPB >= ntiles;
+    const long long vblock = ((JMODE == 1 || JMODE == 2) && one_tile_per_wave) ? (long long)pem::xcd_contiguous_block() : (long long)blockIdx.x;
     const long long me = vblock * WPB + wave, nwaves = (long long)gridDim.x * WPB;
     long long t = me;
     if constexpr (MC) {
