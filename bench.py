@@ -18,6 +18,10 @@ round 2 reported, is carried as `config.single_batch_rerun` for comparison and i
 (default 2, equal, on tile boundaries) pieces and the all-gather of piece k runs beside the evaluation of piece k+1 (hallthrusterpem_amd.distributed.
 ChunkedGather), so a single campaign overlaps its own exchange; `--gather once` is the one-collective-per-campaign
 schedule, `--gather none` skips the exchange, `--gather full` moves the 91-point profiles.
+Before the W untimed warm-up steps the same steps run, untimed, for `--spin-up-ms` (default 30) milliseconds: after an idle
+period the GPU needs about 15 ms of load before a launch takes its steady duration (193 us instead of 210-220,
+tools/warmup_probe.py, profiles/warmup_r03.txt), and a run of W + K = 25 launches would otherwise time that ramp
+(`config.spin_up` says how many steps it took; `--spin-up-ms 0` turns it off).  The timed region is exactly K steps.
 
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (python -m torch.distributed.run,
 as a child process, before anything touches the GPU); under torch.distributed.run it reads RANK / LOCAL_RANK /
@@ -247,6 +251,11 @@ def main():
                          'kernel is VALU-bound and two of its launches side by side take twice as long each: '
                          'profiles/launch_amortisation_r03.txt).  The roofline object always quotes the duration of ISOLATED '
                          'launches; the one-stream rate of the same run is carried as config.single_stream')
+    ap.add_argument('--spin-up-ms', type=float, default=30.0,
+                    help='untimed steps run BEFORE the W warm-up steps until this much time has passed: after an idle period the '
+                         'GPU needs about 15 ms of load before a launch takes its steady 193 us instead of 210-220 '
+                         '(profiles/warmup_r03.txt: the same ramp after 50 ms of idling, so a clock ramp, not first touch); a run '
+                         'of W + K = 25 launches would otherwise time that ramp.  Reported as config.spin_up; 0 = off')
     ap.add_argument('--no-single-batch', action='store_true', help='skip the cache-assisted single-batch comparison run (profiling: every launch is then a rotating one)')
     ap.add_argument('--no-profile', action='store_true', help='reduced-QoI mode: never write j_ion (144 B/eval)')
     ap.add_argument('--mixed', action='store_true', help='fp64 arithmetic, fp32 storage of the profile (508 B/eval)')
@@ -405,6 +414,25 @@ def main():
             dt = float(t.item())
         return dt
 
+    # clock spin-up (see --spin-up-ms): plain steps, no fence between them and the warm-up steps that follow
+    spin_steps = 0
+    if args.spin_up_ms > 0:
+        torch.cuda.synchronize()
+        t_spin = time.perf_counter()
+        while True:
+            for _ in range(8):
+                step()
+            spin_steps += 8
+            if pipe is None:
+                # (the host runs ahead of the GPU: wait for the launches so far, minus a few that keep the queue fed)
+                torch.cuda.current_stream().synchronize() if side is None else side[0].synchronize()
+            done = time.perf_counter() - t_spin >= 1e-3 * args.spin_up_ms
+            if multi:
+                flag = torch.tensor([1 if done else 0], dtype=torch.int64, device=batch.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # every rank takes the same number of steps
+                done = bool(flag.item())
+            if done or spin_steps >= 4096:
+                break
     for _ in range(args.warmup):
         step()
     elapsed = timed(args.steps)
@@ -492,6 +520,9 @@ def main():
                        'samples_per_gpu': n, 'global_samples_per_step': world * n, 'seed': args.seed,
                        'TORR_2_PA': 133.322, 'lanes_per_sample': lanes, 'profile_written': not args.no_profile,
                        'batches_rotated': nb, 'input_layout': args.layout, 'streams': args.streams,
+                       'spin_up': {'steps': spin_steps, 'ms': args.spin_up_ms,
+                                   'note': 'untimed steps before the W warm-up steps: the GPU reaches its steady clocks after about 15 ms '
+                                           'of load (profiles/warmup_r03.txt); --spin-up-ms 0 times the ramp instead'},
                        'single_stream': ({'ms_per_step': 1e3 * elapsed_one_stream / args.steps, 'value': world * n * args.steps / elapsed_one_stream,
                                           'note': 'the same steps on ONE stream, every launch waiting for the one before'}
                                          if elapsed_one_stream else None),

@@ -36,6 +36,12 @@ def test_single_gpu_line():
     assert r['bytes_per_eval'] == 872 and line['config']['samples_per_gpu'] == 131072
     assert abs(line['value'] - 131072 * 4 / (line['ms_per_step'] * 4e-3)) / line['value'] < 1e-9
     assert 'full_config' not in line['config'] and line['config']['gather'] == 'none'
+    # the untimed clock spin-up in front of the warm-up steps is disclosed, and can be turned off
+    assert line['config']['spin_up']['steps'] >= 8 and line['config']['spin_up']['ms'] == 30.0
+    out = subprocess.run([sys.executable, str(ROOT / 'bench.py'), *SMALL, '--no-cpu-baseline', '--spin-up-ms', '0'], capture_output=True,
+                         text=True, cwd=ROOT, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert _one_json_line(out.stdout)['config']['spin_up']['steps'] == 0
     # steps rotate over 8 batches (nothing is re-read from the Infinity Cache); the one-batch rate is reported beside, not as value
     sb = line['config']['single_batch_rerun']
     assert line['config']['batches_rotated'] == 8 and sb['value'] > 0 and 'NOT the headline' in sb['note']

@@ -37,6 +37,18 @@ __global__ __launch_bounds__(256) void writer_once(f64x2* __restrict__ out, long
     }
 }
 
+// E8: one-shot, ONE tile per wave, workgroups that share a XCD (b, b + 8, ...) take one contiguous eighth of the tiles in order
+// (csrc/pem_common.h xcd_contiguous_block: what plume_r1_kernel's profile modes do since round 3)
+__global__ __launch_bounds__(256) void writer_once_xcd(f64x2* __restrict__ out, long long pieces_total, int pieces_per_tile) {
+    const int lane = threadIdx.x & 63;
+    const unsigned q = gridDim.x >> 3, r = gridDim.x & 7, x = blockIdx.x & 7;
+    const long long vb = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (blockIdx.x >> 3);
+    const long long t = vb * 4 + (threadIdx.x >> 6);
+    if ((t + 1) * pieces_per_tile > pieces_total) return;
+    const f64x2 v = {1.0 + lane, 2.0};
+    f64x2* dst = out + t * pieces_per_tile * 64 + lane;
+    for (int p = 0; p < pieces_per_tile; ++p) __builtin_nontemporal_store(v, dst + (long long)p * 64);
+}
 // E1: one-shot, 1 KB per wave, but workgroup b writes chunk perm(b): the address order of the dispatch order is destroyed
 __global__ __launch_bounds__(256) void writer_scrambled(f64x2* __restrict__ out, long long nblocks, long long mult) {
     const int lane = threadIdx.x & 63;
@@ -185,6 +197,13 @@ int main() {
             timeit([&](int i) { hipLaunchKernelGGL(writer_interleaved, dim3((unsigned)(use / (4 * ppt))), dim3(256), 0, 0, buf[i % NB], use, ppt); },
                    what, use * 1024.0);
         }
+    }
+    for (int ppt : {1, 4, 12, 46, 184}) {   // E8: one-shot, XCD-contiguous tile order (non-temporal stores)
+        const long long use = pieces / ppt * ppt, tiles = use / ppt;
+        char what[160];
+        snprintf(what, sizeof what, "E8 one-shot, ONE tile of %3d KB per wave, XCD-contiguous tile order (nt stores)", ppt);
+        timeit([&](int i) { hipLaunchKernelGGL(writer_once_xcd, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, 0, buf[i % NB], use, ppt); }, what,
+               use * 1024.0);
     }
     return 0;
 }
