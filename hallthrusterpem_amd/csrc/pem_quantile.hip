@@ -21,7 +21,10 @@
 // bin is <= everything in a higher one and equal keys share a bin.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <mutex>
 
 #include "pem_common.h"
@@ -575,9 +578,19 @@ __device__ u64 select_from(const List& list, u64 len, u64 rank, u64 top) {
     }
 }
 
-__global__ __launch_bounds__(QBLOCK) void select_kernel(int nt, Target* __restrict__ tg, const u64* __restrict__ cand) {
+// (`incomplete`: a list whose copy pass delivered another number of values than the histogram counted -- the two passes bin
+// the same way, so this says the code is wrong, not the data; the host refuses the result.  It has happened: a version of
+// compact_bracket_kernel that parked its hits in LDS lost one value in a few thousand, and more with hipcc's atomic optimizer
+// aggregating the slot counter -- which showed as percentiles one rank off, in some runs.)
+__global__ __launch_bounds__(QBLOCK) void select_kernel(int nt, Target* __restrict__ tg, const u64* __restrict__ cand, int* __restrict__ incomplete) {
     Target& T = tg[blockIdx.x];
     if (T.done) return;
+    if (threadIdx.x == 0 && T.owner == (int)(blockIdx.x % nt) && T.cursor != T.count && atomicExch(incomplete, 1) == 0) {
+        u64* note = reinterpret_cast<u64*>(incomplete) + 1;               // which list, for the error message
+        note[0] = blockIdx.x;
+        note[1] = T.cursor;
+        note[2] = T.count;
+    }
     const u64* list = cand + T.offset;
     const u64 answer = select_from([list](u64 i) { return list[i]; }, T.count, T.rank, ~0ull);
     if (threadIdx.x == 0) {
@@ -599,6 +612,244 @@ __global__ void finish_kernel(int m, int nq, const Column* __restrict__ col, con
     if (t >= 0.5) r = b - diff * (1.0 - t);
     if (col[c].has_nan || col[c].kmin > col[c].kmax) r = __builtin_nan("");
     out[(size_t)q * m + c] = r;
+}
+
+// ---- the pilot form (round 3): two passes over the data instead of four ------------------------------------------------------
+// The selection above spends its first two passes finding, per wanted rank, a key interval that holds 1/BINS1 of the column.
+// A strided subsample -- every PILOT-th row, 3 % of the data -- gives such an interval for the price of the four passes over
+// the subsample alone: the order statistics of the subsample a few standard deviations either side of the wanted quantile
+// bracket it ("the bracket" [lo, hi] per column and quantile; both ranks numpy reads for a quantile lie in one bracket).
+// Then ONE pass counts, per bracket, the values below it and a histogram inside it (a value outside every bracket costs two
+// compares per bracket and no LDS atomic -- pass 2 above pays one per value), the wanted ranks become (sub-bin, rank inside)
+// exactly as in decide2_kernel, and ONE pass copies the few values of those sub-bins out; lists, sort and interpolation are the
+// ones above.  Exactness does not rest on the subsample: the counts say whether a wanted rank really lies inside its bracket
+// (below <= rank < below + inside), and if any does not -- data ordered so that the strided rows misrepresent it -- the call
+// falls back to the four passes.  The subsample only decides how often that happens: with brackets 7 sigma wide, for
+// exchangeable rows (Monte-Carlo, Latin hypercube and Saltelli designs), about once in 1e9 calls.
+struct Bracket {         // per (column, quantile)
+    u64 lo, span;        // keys lo .. lo + span
+    unsigned mult;       // floor(2^32 bins / ((span >> shift) + 1)), as Column
+    int shift;
+};
+struct PilotEnds {       // a bracket end that would lie outside the subsample is open: the smallest / largest key
+    int open_lo[PEM_QUANTILE_MAX_Q], open_hi[PEM_QUANTILE_MAX_Q];
+};
+
+// brackets from the order statistics of the subsample (targets 2q, 2q + 1 of the pilot run: the lower and the upper end)
+__global__ void brackets_kernel(int m, int nq, const Target* __restrict__ ptg, PilotEnds e, int bins, Bracket* __restrict__ br) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m * nq) return;
+    const int c = i / nq, q = i - c * nq;
+    const u64 lo = e.open_lo[q] ? 0ull : ptg[c * 2 * nq + 2 * q].answer;
+    u64 hi = e.open_hi[q] ? ~0ull : ptg[c * 2 * nq + 2 * q + 1].answer;
+    if (hi < lo) hi = lo;                  // (a subsample column without a finite value: the column's result is NaN anyway)
+    Bracket b;
+    b.lo = lo;
+    b.span = hi - lo;
+    int shift = 0;
+    while ((b.span >> shift) >> 31) ++shift;
+    const u64 mult = (((u64)bins) << 32) / ((b.span >> shift) + 1);
+    b.shift = shift;
+    b.mult = mult > 0xffffffffull ? 0xffffffffu : (unsigned)mult;
+    br[i] = b;
+}
+
+__device__ __forceinline__ int bracket_bin(u64 d, unsigned mult, int shift) { return (int)(((u64)(unsigned)(d >> shift) * mult) >> 32); }
+// the high word of key_of(x) from the high word of x alone (three instructions; the passes below decide nearly every value on it)
+__device__ __forceinline__ unsigned key_high(double x) {
+    const int bh = __double2hiint(x);
+    return (unsigned)bh ^ ((unsigned)(bh >> 31) | 0x80000000u);
+}
+// the smallest d in [0, D + 1] whose bin is >= b (D + 1: none) -- the binning is monotone, so this is where sub-bin b begins
+__device__ __forceinline__ u64 first_d_of_bin(unsigned mult, int b, u64 D) {
+    u64 lo = 0, hi = D + 1;
+    while (lo < hi) {
+        const u64 mid = (lo + hi) >> 1;
+        if ((int)((mid * mult) >> 32) >= b) hi = mid;
+        else lo = mid + 1;
+    }
+    return lo;
+}
+
+// pass A: per (column, quantile) the number of values below the bracket and a histogram of those inside it; NaN per column
+// Up to 128 columns two workgroups share a CU (16 waves: the pass is as much instruction issue as memory): the bracket histogram
+// gets half the LDS (LDS_WORDS_A) and the registers have to fit twice; four columns per lane need them all.
+constexpr int LDS_WORDS_A = 20224;        // 79 KB of 32-bit counters per workgroup
+template <int NC>
+constexpr int bracket_waves_per_simd() { return NC <= 2 ? 4 : 2; }
+template <int NC, int NQ>
+__global__ __launch_bounds__(QBLOCK) __attribute__((amdgpu_waves_per_eu(bracket_waves_per_simd<NC>()))) void bracket_hist_kernel(long long n, int m, size_t ld, const double* __restrict__ data,
+                                                               const Bracket* __restrict__ br, int bins, Column* __restrict__ col,
+                                                               u64* __restrict__ below, unsigned* __restrict__ hist) {
+    extern __shared__ unsigned lds_hist[];                      // [m][NQ][bins] | below [m][NQ]
+    unsigned* lds_below = lds_hist + m * NQ * bins;
+    for (int i = threadIdx.x; i < m * NQ * (bins + 1); i += QBLOCK) lds_hist[i] = 0;
+    __syncthreads();
+    const Lanes L(m, threadIdx.x & 63);
+    u64 blo[NC][NQ], bspan[NC][NQ];
+    unsigned bmult[NC][NQ], nbelow[NC][NQ], bwords[NC][NQ];
+    int bshift[NC][NQ], nan[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const int c = L.col0 + 64 * j;
+        const bool on = L.active && c < m;
+        nan[j] = 0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            blo[j][q] = on ? br[c * NQ + q].lo : 0;
+            bspan[j][q] = on ? br[c * NQ + q].span : 0;
+            bmult[j][q] = on ? br[c * NQ + q].mult : 0;
+            bshift[j][q] = on ? br[c * NQ + q].shift : 0;
+            bwords[j][q] = (unsigned)((blo[j][q] + bspan[j][q]) >> 32) - (unsigned)(blo[j][q] >> 32);
+            nbelow[j][q] = 0;
+        }
+    }
+    // Nearly every value lies outside every bracket, and the HIGH word of its key says so: per bracket a compare-and-count and
+    // a range test in 32 bits, no branch.  Only a key whose high word lies between those of a bracket's ends is looked at in
+    // full (about every other wave instruction holds one: 64 lanes x 3 brackets x 1 %).  A NaN is flagged and otherwise counted
+    // as whatever its bits say: the column's result is NaN whatever the counts are.
+    stream_values<NC>(n, m, ld, data, L, [&](int j, int c, double x) {
+        nan[j] |= x != x ? 1 : 0;
+        const unsigned kh = key_high(x);
+        bool near = false;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const unsigned loh = (unsigned)(blo[j][q] >> 32);
+            nbelow[j][q] += kh < loh ? 1u : 0u;
+            near |= kh - loh <= bwords[j][q];
+        }
+        if (near && x == x) {
+            const u64 k = key_of(x);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if (kh - (unsigned)(blo[j][q] >> 32) <= bwords[j][q]) {
+                    const u64 d = k - blo[j][q];                // wraps above every span when k < lo (then kh == loh)
+                    nbelow[j][q] += k < blo[j][q] ? 1u : 0u;
+                    if (d <= bspan[j][q]) atomicAdd(&lds_hist[(c * NQ + q) * bins + bracket_bin(d, bmult[j][q], bshift[j][q])], 1u);
+                }
+            }
+        }
+    });
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const int c = L.col0 + 64 * j;
+        if (L.active && c < m) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                if (nbelow[j][q]) atomicAdd(&lds_below[c * NQ + q], nbelow[j][q]);
+            if (nan[j]) atomicOr(&col[c].has_nan, 1);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < m * NQ * bins; i += QBLOCK) {
+        const unsigned v = lds_hist[i];
+        if (v) atomicAdd(&hist[i], v);
+    }
+    for (int i = threadIdx.x; i < m * NQ; i += QBLOCK) {
+        const unsigned v = lds_below[i];
+        if (v) atomicAdd(&below[i], (u64)v);
+    }
+}
+
+// one wave per (column, target): is the rank inside its bracket, and if so in which sub-bin (decide2_kernel's role; bin1 = the
+// quantile, so that layout_kernel's "same bin and sub-bin" is "same bracket and sub-bin")
+__global__ __launch_bounds__(64) void decide_bracket_kernel(int nt, Column* __restrict__ col, const Bracket* __restrict__ br,
+                                                             const u64* __restrict__ below, const unsigned* __restrict__ hist, int bins,
+                                                             Target* __restrict__ tg, int* __restrict__ outside) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const int c = i / nt, t = i - c * nt, q = t >> 1, nq = nt >> 1;
+    Target T = tg[i];
+    if (t == 0 && lane == 0) {             // finish_kernel reads kmin > kmax as "no finite value": every such column holds a NaN here
+        col[c].kmin = 0ull;
+        col[c].kmax = ~0ull;
+    }
+    T.owner = t;
+    if (col[c].has_nan) {                   // the column's result is NaN whatever the ranks are
+        T.done = 1;
+        T.answer = 0;
+    } else {
+        const Bracket b = br[c * nq + q];
+        const u64 lowc = below[c * nq + q];
+        const u64 r = T.rank - lowc;
+        const Found f = find_bin(hist + (size_t)(c * nq + q) * bins, bins, r, lane);
+        if (T.rank < lowc || f.before + f.count <= r) {      // not in the bracket: the call falls back to the four passes
+            T.done = 1;
+            T.answer = 0;
+            if (lane == 0) atomicExch(outside, 1);
+        } else if (b.span == 0) {          // a bracket of one key (a constant column): the answer is that key
+            T.done = 1;
+            T.answer = b.lo;
+        } else {
+            T.bin1 = q;
+            T.bin2 = f.bin;
+            T.rank = r - f.before;
+            T.count = f.count;
+        }
+    }
+    if (lane == 0) tg[i] = T;
+}
+
+// pass B: copy out the values of the chosen sub-bins.  (Parking the hits in LDS and appending them after the last row, so that no
+// wave waits for a global atomic in mid-stream, measured the same 1.67 ms as appending on the spot: not kept.)
+template <int NC, int NQ>
+__global__ __launch_bounds__(QBLOCK) void compact_bracket_kernel(long long n, int m, size_t ld, const double* __restrict__ data,
+                                                                  const Bracket* __restrict__ br, Target* __restrict__ tg,
+                                                                  u64* __restrict__ cand) {
+    constexpr int NT = 2 * NQ;
+    const Lanes L(m, threadIdx.x & 63);
+    // per (column, quantile): the key range of the sub-bins its list owners collect (two adjacent ranks: one sub-bin, or two
+    // neighbours), found from the binning itself; a value is tested against its high words only
+    u64 rlo[NC][NQ], rspan[NC][NQ];
+    unsigned rwords[NC][NQ];
+    int tb2[NC][NT];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const int c = L.col0 + 64 * j;
+        const bool on = L.active && c < m;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            u64 lo = ~0ull, hi = 0ull;
+#pragma unroll
+            for (int t = 2 * q; t < 2 * q + 2; ++t) {
+                const bool own = on && !tg[c * NT + t].done && tg[c * NT + t].owner == t;   // only list owners collect
+                tb2[j][t] = own ? tg[c * NT + t].bin2 : -1;
+                if (own) {
+                    const Bracket B = br[c * NQ + q];
+                    const u64 D = B.span >> B.shift;
+                    const u64 d0 = first_d_of_bin(B.mult, tb2[j][t], D), d1 = first_d_of_bin(B.mult, tb2[j][t] + 1, D);
+                    const u64 k0 = B.lo + (d0 << B.shift), k1 = d1 > D ? B.lo + B.span : B.lo + (d1 << B.shift) - 1;
+                    lo = k0 < lo ? k0 : lo;
+                    hi = k1 > hi ? k1 : hi;
+                }
+            }
+            if (lo > hi) lo = hi = ~0ull;                       // no owner: a range no value's key lies in
+            rlo[j][q] = lo;
+            rspan[j][q] = hi - lo;
+            rwords[j][q] = (unsigned)(hi >> 32) - (unsigned)(lo >> 32);
+        }
+    }
+    stream_values<NC>(n, m, ld, data, L, [&](int j, int c, double x) {
+        const unsigned kh = key_high(x);
+        bool near = false;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) near |= kh - (unsigned)(rlo[j][q] >> 32) <= rwords[j][q];
+        if (near && x == x) {                                   // (about one wave instruction in ten)
+            const u64 k = key_of(x);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if (k - rlo[j][q] <= rspan[j][q]) {
+                    const Bracket B = br[c * NQ + q];
+                    const int b = bracket_bin(k - B.lo, B.mult, B.shift);
+                    // (the two targets of a quantile share a list when they share the sub-bin: at most one of them owns it)
+                    const int hit = tb2[j][2 * q] == b ? 2 * q : (tb2[j][2 * q + 1] == b ? 2 * q + 1 : -1);
+                    if (hit >= 0) {
+                        Target& T = tg[c * NT + hit];
+                        cand[T.offset + atomicAdd(&T.cursor, 1ull)] = k;
+                    }
+                }
+            }
+        }
+    });
 }
 
 // ---- the multi-rank form: histograms over caller-given key ranges -----------------------------------------------------------
@@ -705,6 +956,11 @@ int pow2_at_most(long long x, int cap) {
 
 }  // namespace
 
+// which way the last call of pem_quantiles_f64_dev went: 0 four passes, 1 pilot + two passes, 2 pilot, then four passes (a
+// wanted rank outside its bracket)
+static std::atomic<int> g_last_path{0};
+extern "C" int pem_quantiles_last_path(void) { return g_last_path.load(); }
+
 extern "C" int pem_quantiles_f64_dev(size_t n, int m, const double* data, size_t ld, int nq, const uint64_t* rank_prev, const uint64_t* rank_next,
                                      const double* gamma, double* out, pem_stream_t stream) {
     if (m < 1 || m > 64 * MAX_NC) return pem::fail(PEM_ERR_INVALID_ARG, "pem_quantiles: 1 <= m <= %d columns", 64 * MAX_NC);
@@ -719,13 +975,25 @@ extern "C" int pem_quantiles_f64_dev(size_t n, int m, const double* data, size_t
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int nt = 2 * nq;
     const int bins1 = pow2_at_most(LDS_WORDS / m, 4096), bins2 = pow2_at_most(LDS_WORDS / (m * nt), 4096);
+    int binsA = pow2_at_most((m <= 128 ? LDS_WORDS_A : LDS_WORDS) / (m * nq) - 1, 4096);   // the pilot form's histogram inside a bracket (+ 1 counter)
+    if (const char* e = getenv("PEM_QUANTILE_BINSA")) binsA = pow2_at_most(atoll(e) < binsA ? atoll(e) : binsA, 4096);
 
-    // workspace: columns | targets | hist1 | hist2 | total -- kept between calls (grow-only, one per process; calls are
-    // serialised on it, and each one ends with a stream synchronisation before the next may touch it)
+    // the pilot form: every `pilot`-th row brackets the wanted ranks (PEM_QUANTILE_PILOT: the stride, 0 = never;
+    // PEM_QUANTILE_PILOT_MIN: the smallest n * m it is used for -- 1e7 x 1 takes 0.24 ms with the four passes and 0.32 with the
+    // pilot's dozen launches in front of two, 1e7 x 3 the same either way, 6e5 x 91 0.60 against 0.56: profiles/quantile_pilot_r03.txt)
+    long long pilot = 32, pilot_min = 1 << 25;
+    if (const char* e = getenv("PEM_QUANTILE_PILOT")) pilot = atoll(e);
+    if (const char* e = getenv("PEM_QUANTILE_PILOT_MIN")) pilot_min = atoll(e);
+    const bool use_pilot = pilot >= 2 && (long long)n * m >= pilot_min && (long long)n >= 4 * pilot;
+
+    // workspace: columns | targets | hist1 | hist2 | total, outside | brackets | below | histA -- kept between calls (grow-only,
+    // one per process; calls are serialised on it, and each one ends with a stream synchronisation before the next may touch it)
     const size_t b_col = sizeof(Column) * m, b_tg = sizeof(Target) * m * nt;
     const size_t b_h1 = sizeof(unsigned) * (size_t)m * bins1, b_h2 = sizeof(unsigned) * (size_t)m * nt * bins2;
+    const size_t b_br = sizeof(Bracket) * m * nq, b_bl = sizeof(u64) * m * nq, b_hA = sizeof(unsigned) * (size_t)m * nq * binsA;
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t o_tg = up(b_col), o_h1 = o_tg + up(b_tg), o_h2 = o_h1 + up(b_h1), o_tot = o_h2 + up(b_h2);
+    const size_t o_br = o_tot + 256, o_bl = o_br + up(b_br), o_hA = o_bl + up(b_bl), o_end = o_hA + up(b_hA);
     static std::mutex mu;
     static char* ws_buf = nullptr;
     static size_t ws_cap = 0, cand_cap = 0;
@@ -734,7 +1002,7 @@ extern "C" int pem_quantiles_f64_dev(size_t n, int m, const double* data, size_t
     std::lock_guard<std::mutex> lock(mu);
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    if (dev != ws_dev || ws_cap < o_tot + 256) {
+    if (dev != ws_dev || ws_cap < o_end) {
         if (ws_buf) (void)hipFree(ws_buf);
         if (cand_buf && dev != ws_dev) {
             (void)hipFree(cand_buf);
@@ -743,8 +1011,8 @@ extern "C" int pem_quantiles_f64_dev(size_t n, int m, const double* data, size_t
         }
         ws_buf = nullptr;
         ws_cap = 0;
-        HIP_TRY(hipMalloc(&ws_buf, o_tot + 256));
-        ws_cap = o_tot + 256;
+        HIP_TRY(hipMalloc(&ws_buf, o_end));
+        ws_cap = o_end;
         ws_dev = dev;
     }
     char* ws = ws_buf;
@@ -752,7 +1020,12 @@ extern "C" int pem_quantiles_f64_dev(size_t n, int m, const double* data, size_t
     Target* tg = reinterpret_cast<Target*>(ws + o_tg);
     unsigned* hist1 = reinterpret_cast<unsigned*>(ws + o_h1);
     unsigned* hist2 = reinterpret_cast<unsigned*>(ws + o_h2);
-    u64* total = reinterpret_cast<u64*>(ws + o_tot);
+    u64* total = reinterpret_cast<u64*>(ws + o_tot);                       // total[0]: candidates; total[1] (as int): a rank outside its bracket
+    int* outside = reinterpret_cast<int*>(total + 1);
+    int* incomplete = reinterpret_cast<int*>(total + 2);                   // a list shorter or longer than counted (select_kernel)
+    Bracket* br = reinterpret_cast<Bracket*>(ws + o_br);
+    u64* below = reinterpret_cast<u64*>(ws + o_bl);
+    unsigned* histA = reinterpret_cast<unsigned*>(ws + o_hA);
     auto cleanup = [&](int code) {
         (void)hipStreamSynchronize(st);
         return code;
@@ -769,15 +1042,25 @@ extern "C" int pem_quantiles_f64_dev(size_t n, int m, const double* data, size_t
         w.next[q] = rank_next[q];
         w.gamma[q] = gamma[q];
     }
-    Q_TRY(hipMemsetAsync(hist1, 0, o_tot + 256 - o_h1, st));            // hist1, hist2, total
-
-    const long long rpw = m <= 64 ? 64 / m : 1, groups = ((long long)n + rpw - 1) / rpw;
-    long long blocks = (groups + (long long)QWAVES * UNROLL - 1) / ((long long)QWAVES * UNROLL);
-    if (blocks > 256 * 2) blocks = 256 * 2;
-    const dim3 grid((unsigned)blocks), blk(QBLOCK);
     const int cblocks = (m + 63) / 64;
     const int nc = m <= 64 ? 1 : (m <= 128 ? 2 : 4);
-    const size_t lds1 = (size_t)m * bins1 * 4, lds2 = (size_t)m * nt * bins2 * 4;
+    const size_t lds1 = (size_t)m * bins1 * 4, lds2 = (size_t)m * nt * bins2 * 4, ldsA = (size_t)m * nq * (binsA + 1) * 4;
+    const dim3 blk(QBLOCK);
+    auto grid_for = [&](size_t rows) {
+        const long long rpw = m <= 64 ? 64 / m : 1, groups = ((long long)rows + rpw - 1) / rpw;
+        long long blocks = (groups + (long long)QWAVES * UNROLL - 1) / ((long long)QWAVES * UNROLL);
+        if (blocks > 256 * 2) blocks = 256 * 2;
+        return dim3((unsigned)blocks);
+    };
+    auto grow_candidates = [&](u64 need) -> hipError_t {
+        if (cand_cap >= need + 1) return hipSuccess;
+        if (cand_buf) (void)hipFree(cand_buf);
+        cand_buf = nullptr;
+        cand_cap = 0;
+        const hipError_t e = hipMalloc(&cand_buf, (size_t)(need + 1) * sizeof(u64));
+        if (e == hipSuccess) cand_cap = need + 1;
+        return e;
+    };
 #define Q_LDS(KERN) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
 #define Q_BY_NC(CALL)              \
     do {                           \
@@ -791,54 +1074,129 @@ extern "C" int pem_quantiles_f64_dev(size_t n, int m, const double* data, size_t
         else if (nt == 4) { CALL(NC_, 4); } \
         else { CALL(NC_, 6); }         \
     } while (0)
-    hipLaunchKernelGGL(init_columns_kernel, dim3(cblocks), dim3(64), 0, st, col, tg, m, nq, w);
-#define Q_MINMAX(NC_) hipLaunchKernelGGL(minmax_kernel<NC_>, grid, blk, 0, st, (long long)n, m, ld, data, col)
-    Q_BY_NC(Q_MINMAX);
-    hipLaunchKernelGGL(scale_columns_kernel, dim3(cblocks), dim3(64), 0, st, col, m, bins1);
+#define Q_BY_NQ(CALL, NC_)             \
+    do {                               \
+        if (nq == 1) { CALL(NC_, 1); } \
+        else if (nq == 2) { CALL(NC_, 2); } \
+        else { CALL(NC_, 3); }         \
+    } while (0)
+
+    // the four passes over rows 0, step, 2 step, ... (`rows` of them, leading dimension ldd): x_(rank) of every target ends in tg[].answer
+    auto four_passes = [&](size_t rows, size_t ldd, const Wanted& ww) -> int {
+        const dim3 grid = grid_for(rows);
+        Q_TRY(hipMemsetAsync(hist1, 0, o_tot + 256 - o_h1, st));            // hist1, hist2, total
+        hipLaunchKernelGGL(init_columns_kernel, dim3(cblocks), dim3(64), 0, st, col, tg, m, nq, ww);
+#define Q_MINMAX(NC_) hipLaunchKernelGGL(minmax_kernel<NC_>, grid, blk, 0, st, (long long)rows, m, ldd, data, col)
+        Q_BY_NC(Q_MINMAX);
+        hipLaunchKernelGGL(scale_columns_kernel, dim3(cblocks), dim3(64), 0, st, col, m, bins1);
 #define Q_HIST1(NC_)                                                                                       \
     Q_LDS(hist1_kernel<NC_>);                                                                              \
-    hipLaunchKernelGGL(hist1_kernel<NC_>, grid, blk, lds1, st, (long long)n, m, ld, data, col, bins1, hist1)
-    Q_BY_NC(Q_HIST1);
-    hipLaunchKernelGGL(decide1_kernel, dim3((unsigned)(m * nt)), dim3(64), 0, st, m, nt, col, hist1, bins1, tg);
+    hipLaunchKernelGGL(hist1_kernel<NC_>, grid, blk, lds1, st, (long long)rows, m, ldd, data, col, bins1, hist1)
+        Q_BY_NC(Q_HIST1);
+        hipLaunchKernelGGL(decide1_kernel, dim3((unsigned)(m * nt)), dim3(64), 0, st, m, nt, col, hist1, bins1, tg);
 #define Q_HIST2_(NC_, NT_)                                                                                                  \
     Q_LDS((hist2_kernel<NC_, NT_>));                                                                                        \
-    hipLaunchKernelGGL((hist2_kernel<NC_, NT_>), grid, blk, lds2, st, (long long)n, m, ld, data, col, tg, bins1, bins2, hist2)
+    hipLaunchKernelGGL((hist2_kernel<NC_, NT_>), grid, blk, lds2, st, (long long)rows, m, ldd, data, col, tg, bins1, bins2, hist2)
 #define Q_HIST2(NC_) Q_BY_NT(Q_HIST2_, NC_)
-    Q_BY_NC(Q_HIST2);
-    hipLaunchKernelGGL(decide2_kernel, dim3((unsigned)(m * nt)), dim3(64), 0, st, nt, hist2, bins2, tg);
-    hipLaunchKernelGGL(layout_kernel, dim3(1), dim3(64 * MAX_NC), 0, st, m, nt, tg, total);
-    Q_TRY(hipGetLastError());
-    u64 h_total = 0;
-    Q_TRY(hipMemcpyAsync(&h_total, total, sizeof(u64), hipMemcpyDeviceToHost, st));
-    Q_TRY(hipStreamSynchronize(st));
-    if (cand_cap < h_total + 1) {
-        if (cand_buf) (void)hipFree(cand_buf);
-        cand_buf = nullptr;
-        cand_cap = 0;
-        Q_TRY(hipMalloc(&cand_buf, (size_t)(h_total + 1) * sizeof(u64)));
-        cand_cap = h_total + 1;
-    }
-    u64* cand = cand_buf;
+        Q_BY_NC(Q_HIST2);
+        hipLaunchKernelGGL(decide2_kernel, dim3((unsigned)(m * nt)), dim3(64), 0, st, nt, hist2, bins2, tg);
+        hipLaunchKernelGGL(layout_kernel, dim3(1), dim3(64 * MAX_NC), 0, st, m, nt, tg, total);
+        Q_TRY(hipGetLastError());
+        u64 h_total = 0;
+        Q_TRY(hipMemcpyAsync(&h_total, total, sizeof(u64), hipMemcpyDeviceToHost, st));
+        Q_TRY(hipStreamSynchronize(st));
+        Q_TRY(grow_candidates(h_total));
+        u64* cand = cand_buf;
 #define Q_COMPACT_(NC_, NT_) \
-    hipLaunchKernelGGL((compact_kernel<NC_, NT_>), grid, blk, 0, st, (long long)n, m, ld, data, col, tg, bins1, bins2, cand)
+    hipLaunchKernelGGL((compact_kernel<NC_, NT_>), grid, blk, 0, st, (long long)rows, m, ldd, data, col, tg, bins1, bins2, cand)
 #define Q_COMPACT(NC_) Q_BY_NT(Q_COMPACT_, NC_)
-    Q_BY_NC(Q_COMPACT);
-    hipLaunchKernelGGL(select_kernel, dim3((unsigned)(m * nt)), blk, 0, st, nt, tg, cand);
+        Q_BY_NC(Q_COMPACT);
+        hipLaunchKernelGGL(select_kernel, dim3((unsigned)(m * nt)), blk, 0, st, nt, tg, cand, incomplete);
+        Q_TRY(hipGetLastError());
+        return PEM_OK;
+    };
+
+    int path = 0;
+    bool answered = false;
+    if (use_pilot) {
+        // 1. the subsample's order statistics around every wanted quantile: 7 standard deviations of the subsample's rank, + 8
+        const size_t rows_p = (n + (size_t)pilot - 1) / (size_t)pilot;
+        Wanted pw{};
+        PilotEnds ends{};
+        const double n1 = n > 1 ? (double)(n - 1) : 1.0, np1 = (double)(rows_p - 1);
+        for (int q = 0; q < nq; ++q) {
+            const double p_lo = (double)rank_prev[q] / n1, p_hi = (double)rank_next[q] / n1;
+            const double d_lo = 7.0 * sqrt((double)rows_p * p_lo * (1.0 - p_lo)) + 8.0, d_hi = 7.0 * sqrt((double)rows_p * p_hi * (1.0 - p_hi)) + 8.0;
+            const double r_lo = floor(p_lo * np1 - d_lo) - 1.0, r_hi = ceil(p_hi * np1 + d_hi) + 1.0;
+            ends.open_lo[q] = r_lo < 0.0;
+            ends.open_hi[q] = r_hi > np1;
+            pw.prev[q] = ends.open_lo[q] ? 0 : (u64)r_lo;
+            pw.next[q] = ends.open_hi[q] ? (u64)(rows_p - 1) : (u64)r_hi;
+        }
+        if (int rc = four_passes(rows_p, ld * (size_t)pilot, pw)) return rc;
+        hipLaunchKernelGGL(brackets_kernel, dim3((unsigned)((m * nq + 63) / 64)), dim3(64), 0, st, m, nq, tg, ends, binsA, br);
+        // 2. pass A over everything: below / inside counts; the ranks inside their brackets become sub-bins
+        const dim3 grid = grid_for(n);
+        Q_TRY(hipMemsetAsync(total, 0, 256, st));                           // total, outside
+        Q_TRY(hipMemsetAsync(below, 0, o_end - o_bl, st));                  // below, histA
+        hipLaunchKernelGGL(init_columns_kernel, dim3(cblocks), dim3(64), 0, st, col, tg, m, nq, w);
+#define Q_BRHIST_(NC_, NQ_)                                                                                                  \
+    Q_LDS((bracket_hist_kernel<NC_, NQ_>));                                                                                  \
+    hipLaunchKernelGGL((bracket_hist_kernel<NC_, NQ_>), grid, blk, ldsA, st, (long long)n, m, ld, data, br, binsA, col, below, histA)
+#define Q_BRHIST(NC_) Q_BY_NQ(Q_BRHIST_, NC_)
+        Q_BY_NC(Q_BRHIST);
+        hipLaunchKernelGGL(decide_bracket_kernel, dim3((unsigned)(m * nt)), dim3(64), 0, st, nt, col, br, below, histA, binsA, tg, outside);
+        hipLaunchKernelGGL(layout_kernel, dim3(1), dim3(64 * MAX_NC), 0, st, m, nt, tg, total);
+        Q_TRY(hipGetLastError());
+        u64 h_tot[2] = {0, 0};
+        Q_TRY(hipMemcpyAsync(h_tot, total, 2 * sizeof(u64), hipMemcpyDeviceToHost, st));
+        Q_TRY(hipStreamSynchronize(st));
+        if ((int)(h_tot[1] & 0xffffffffull) == 0) {
+            // 3. pass B: the values of those sub-bins, then the lists as in the four-pass form
+            Q_TRY(grow_candidates(h_tot[0]));
+            u64* cand = cand_buf;
+#define Q_BRCOMPACT_(NC_, NQ_) \
+    hipLaunchKernelGGL((compact_bracket_kernel<NC_, NQ_>), grid, blk, 0, st, (long long)n, m, ld, data, br, tg, cand)
+#define Q_BRCOMPACT(NC_) Q_BY_NQ(Q_BRCOMPACT_, NC_)
+            Q_BY_NC(Q_BRCOMPACT);
+            hipLaunchKernelGGL(select_kernel, dim3((unsigned)(m * nt)), blk, 0, st, nt, tg, cand, incomplete);
+            Q_TRY(hipGetLastError());
+            answered = true;
+            path = 1;
+        } else {
+            path = 2;
+        }
+    }
+    if (!answered)
+        if (int rc = four_passes(n, ld, w)) return rc;
     hipLaunchKernelGGL(finish_kernel, dim3((unsigned)((m * nq + 63) / 64)), dim3(64), 0, st, m, nq, col, tg, w, out);
     Q_TRY(hipGetLastError());
+    u64 h_incomplete[4] = {0, 0, 0, 0};
+    Q_TRY(hipMemcpyAsync(h_incomplete, incomplete, sizeof h_incomplete, hipMemcpyDeviceToHost, st));
+    Q_TRY(hipStreamSynchronize(st));
+    if (h_incomplete[0] & 0xffffffffull)
+        return pem::fail(PEM_ERR_HIP,
+                         "pem_quantiles: the list of column %llu, rank %llu holds %llu values where %llu were counted (internal error; result "
+                         "discarded; path %d)",
+                         h_incomplete[1] / nt, h_incomplete[1] % nt, h_incomplete[2], h_incomplete[3], path);
+    g_last_path.store(path);
+#undef Q_BRCOMPACT
+#undef Q_BRCOMPACT_
+#undef Q_BRHIST
+#undef Q_BRHIST_
 #undef Q_COMPACT
 #undef Q_COMPACT_
 #undef Q_HIST2
 #undef Q_HIST2_
 #undef Q_HIST1
 #undef Q_MINMAX
+#undef Q_BY_NQ
 #undef Q_BY_NT
 #undef Q_BY_NC
 #undef Q_LDS
 #undef Q_TRY
     return cleanup(PEM_OK);
 }
-
 
 // ---- multi-rank building blocks (one level each; hallthrusterpem_amd/percentiles.py) ---------------------------------------
 namespace {

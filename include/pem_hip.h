@@ -289,10 +289,15 @@ int pem_sparse_grid_values_f64_dev(size_t n, int n_dim, int n_beta, const int32_
  * fully coalesced); for quantile i the caller gives the two ranks
  * numpy's method 'linear' reads (rank_prev[i] <= rank_next[i] < n) and its weight gamma[i] (HOST arrays);
  * out[i][c] = _lerp(x_(rank_prev[i]), x_(rank_next[i]), gamma[i]) of column c, NaN if the column holds a NaN -- equal to
- * np.percentile bit for bit.  nq <= PEM_QUANTILE_MAX_Q per call.  Allocates its workspace and synchronises the stream.   */
+ * np.percentile bit for bit.  nq <= PEM_QUANTILE_MAX_Q per call.  Allocates its workspace and synchronises the stream.
+ * From n * m = 2^25 values on, every 32nd row is examined first and brackets the wanted ranks, which leaves two passes over the
+ * data instead of four; a call whose data defeat the brackets (the counts say so) repeats with the four passes -- the result is
+ * the same either way.  Environment: PEM_QUANTILE_PILOT = that stride (0: never), PEM_QUANTILE_PILOT_MIN = the smallest n * m it
+ * is used for.  pem_quantiles_last_path(): how the last call went (0 four passes, 1 brackets held, 2 brackets failed, four passes).   */
 #define PEM_QUANTILE_MAX_Q 3
 int pem_quantiles_f64_dev(size_t n, int m, const double* data, size_t ld, int nq, const uint64_t* rank_prev, const uint64_t* rank_next,
                           const double* gamma, double* out, pem_stream_t stream);
+int pem_quantiles_last_path(void);
 
 /* The multi-rank building blocks of the same selection (samples sharded over GPUs; hallthrusterpem_amd/percentiles.py drives the
  * levels and all-reduces between them): per-column min / max of the order-preserving 64-bit image of the values (sign bit

@@ -50,6 +50,96 @@ def test_ties_constants_and_special_values():
     _check(d, [25.0, 50.0, 75.0])
 
 
+def _last_path():
+    from hallthrusterpem_amd import _lib
+    return _lib.load().pem_quantiles_last_path()
+
+
+@pytest.fixture
+def pilot_from(monkeypatch):
+    """The pilot form of the selection (every 32nd row brackets the ranks, two passes over the data) is used from 2^19 rows on;
+    the fixture lowers that threshold so that small cases take it too."""
+    def set_min(n, stride=None):
+        monkeypatch.setenv('PEM_QUANTILE_PILOT_MIN', str(n))
+        if stride is not None:
+            monkeypatch.setenv('PEM_QUANTILE_PILOT', str(stride))
+    return set_min
+
+
+@pytest.mark.parametrize('shape', [(129, 1), (4_000, 64), (4_000, 65), (40_000, 91), (3_000, 129), (2_000, 256), (600_000, 91), (2_000_000, 3)])
+def test_pilot_form_equals_numpy(shape, pilot_from):
+    pilot_from(128)
+    rng = np.random.default_rng(sum(shape) + 1)
+    a = rng.lognormal(0.0, 3.0, shape) * np.where(rng.random(shape) < 0.3, -1.0, 1.0)
+    for pcts in ([25.0, 75.0], [5.0, 50.0, 95.0], 50.0, [100.0, 0.0, 33.3, 99.999, 1e-3]):
+        _check(a, pcts)
+        assert _last_path() == 1, (shape, pcts)             # exchangeable rows: the brackets hold
+
+
+def test_pilot_form_ties_constants_and_special_values(pilot_from):
+    pilot_from(128)
+    rng = np.random.default_rng(6)
+    n = 300_000
+    a = rng.lognormal(0.0, 1.0, (n, 7))
+    a[:, 0] = 7.25                                           # a constant column: a bracket of one key
+    a[rng.random(n) < 0.4, 1] = 1e-20                       # 40 % ties at the minimum
+    a[:, 2] = rng.integers(0, 5, n)                         # five distinct values
+    a[::7, 3] = np.inf
+    a[1::7, 3] = -np.inf
+    a[:, 4] = np.where(rng.random(n) < 0.5, 0.0, -0.0)
+    a[12345, 5] = np.nan                                     # a NaN in a row the pilot does not see
+    a[64, 6] = np.nan                                        # ... and one in a row it does
+    for pcts in ([25.0, 75.0], [5.0, 50.0, 95.0], [0.0, 10.0, 40.0, 100.0]):
+        _check(a, pcts)
+        assert _last_path() == 1
+    b = np.full((1000, 3), np.nan)
+    b[:, 1] = 1.0
+    _check(b, [25.0, 75.0])
+    d = rng.standard_normal((4097, 2))
+    d[:, 0] *= 1e-310
+    d[::2, 1] *= 1e300
+    _check(d, [25.0, 50.0, 75.0])
+
+
+def test_pilot_form_with_many_hits_per_wave_instruction(pilot_from):
+    """A tiny array under a forced pilot: 126 pilot rows leave brackets that are open at one end, their sub-bins hold thousands
+    of the 4001 values, and most wave instructions of the copy pass hold several hits.  The case in which a version of that
+    pass that parked its hits in LDS lost values (the library now checks every list's length against its count)."""
+    pilot_from(128)
+    rng = np.random.default_rng(3)
+    a = np.stack([rng.permutation(4001).astype(np.float64) for _ in range(64)], axis=1)
+    for _ in range(2):
+        for pcts in ([25.0, 75.0], 50.0, [12.5, 37.5, 62.5]):
+            _check(a, pcts)
+            assert _last_path() == 1
+
+
+def test_pilot_form_on_ordered_data_and_its_fallback(pilot_from):
+    """Sorted and periodic data: a strided subsample represents a sorted column exactly, so the brackets hold; rows whose
+    every 32nd member is an outlier defeat them -- the counts of pass A say so and the call repeats with the four passes.
+    Either way the result is np.percentile's."""
+    pilot_from(128)
+    rng = np.random.default_rng(8)
+    n = 200_000
+    a = np.sort(rng.standard_normal((n, 5)), axis=0)
+    a[:, 1] = a[::-1, 1]
+    _check(a, [5.0, 50.0, 95.0])
+    assert _last_path() == 1
+    b = rng.standard_normal((n, 4))
+    b[::32, 2] = 1e6 + rng.random(b[::32, 2].shape)          # the pilot sees nothing but these in column 2
+    for pcts in ([25.0, 75.0], [5.0, 50.0, 95.0]):
+        _check(b, pcts)
+        assert _last_path() == 2
+    _check(b, 0.0)                                           # the minimum: its bracket is open below and holds it whatever the pilot saw
+    assert _last_path() == 1
+    pilot_from(128, stride=0)                                # switched off
+    _check(b, [25.0, 75.0])
+    assert _last_path() == 0
+    pilot_from(128, stride=7)                                # another stride: column 2 is ordinary again
+    _check(b, [25.0, 75.0])
+    assert _last_path() == 1
+
+
 def test_filter_outputs_on_the_device_equals_the_host_path_at_a_size_torch_quantile_refuses():
     """drivers.filter_outputs (gen_data.py:125-174) on CUDA tensors goes through the selection kernel: identical masks to the
     numpy branch, also where one column is longer than torch.quantile's 2^24 limit."""
