@@ -6,7 +6,7 @@ from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
-SRCS = [PKG / 'csrc' / 'pem_kernels.hip', PKG / 'csrc' / 'pem_sampler.hip', PKG / 'csrc' / 'pem_svd.hip', PKG / 'csrc' / 'pem_likelihood.hip', PKG / 'csrc' / 'pem_surrogate.hip', PKG / 'csrc' / 'pem_fp32.hip', PKG / 'csrc' / 'pem_saltelli.hip', PKG / 'csrc' / 'pem_latent.hip', PKG / 'csrc' / 'pem_quantile.hip']
+SRCS = [PKG / 'csrc' / 'pem_kernels.hip', PKG / 'csrc' / 'pem_sampler.hip', PKG / 'csrc' / 'pem_svd.hip', PKG / 'csrc' / 'pem_likelihood.hip', PKG / 'csrc' / 'pem_surrogate.hip', PKG / 'csrc' / 'pem_fp32.hip', PKG / 'csrc' / 'pem_saltelli.hip', PKG / 'csrc' / 'pem_latent.hip', PKG / 'csrc' / 'pem_quantile.hip', PKG / 'csrc' / 'pem_masks.hip']
 LIB = PKG / 'libpem_hip.so'
 DEPS = SRCS + sorted((PKG / 'csrc').glob('*.h')) + [ROOT / 'include' / 'pem_hip.h']
 

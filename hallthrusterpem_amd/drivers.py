@@ -71,6 +71,30 @@ def column_percentiles(a, percentiles):
 
 
 # ------------------------------------------------------------------------------------------- NaN / outlier masks
+ROW_MASKS_MAX_M = 512       # include/pem_hip.h PEM_ROW_MASKS_MAX_M
+
+
+def _row_masks(a, lo, hi, per_sample: int):
+    """`np.any(np.isnan(a), axis=rest)` and `np.sum((a < lo) | (a > hi), axis=rest)` of a CUDA tensor (n, ...) against per-entry
+    bounds, in one pass (`pem_row_masks_f64_dev`): (bool tensor (n,), int32 tensor (n,))."""
+    import ctypes as C
+    import torch
+    from . import _lib
+    n = int(a.shape[0])
+    flat = a.reshape(n, per_sample)
+    if not flat.is_contiguous():
+        flat = flat.contiguous()
+    lo = lo.reshape(per_sample).contiguous()
+    hi = hi.reshape(per_sample).contiguous()
+    nan = torch.empty(n, dtype=torch.uint8, device=flat.device)
+    count = torch.empty(n, dtype=torch.int32, device=flat.device)
+    with torch.cuda.device(flat.device):
+        stream = C.c_void_p(torch.cuda.current_stream(flat.device).cuda_stream)
+        _lib.check(_lib.load().pem_row_masks_f64_dev(n, per_sample, C.c_void_p(flat.data_ptr()), per_sample, C.c_void_p(lo.data_ptr()),
+                                                     C.c_void_p(hi.data_ptr()), C.c_void_p(nan.data_ptr()), C.c_void_p(count.data_ptr()), stream))
+    return nan.bool(), count
+
+
 def filter_outputs(outputs: dict, iqr_factor: float = 1.5):
     """NaN and interquartile-range outlier masks per output variable; mirrors gen_data.py:125-174.
 
@@ -89,11 +113,15 @@ def filter_outputs(outputs: dict, iqr_factor: float = 1.5):
             a = arr.double()
             rest = tuple(range(1, a.dim()))
             per_sample = int(np.prod(a.shape[1:])) if a.dim() > 1 else 1
-            nan_idx[var] = torch.isnan(a).any(dim=rest) if rest else torch.isnan(a)
             q = column_percentiles(a, [25.0, 75.0]) if a.is_cuda else torch.quantile(a, torch.tensor([0.25, 0.75], dtype=a.dtype), dim=0)
             iqr = q[1] - q[0]
-            outside = (a < q[0] - iqr_factor * iqr) | (a > q[1] + iqr_factor * iqr)
-            count = outside.sum(dim=rest) if rest else outside.long()
+            lo, hi = q[0] - iqr_factor * iqr, q[1] + iqr_factor * iqr
+            if a.is_cuda and a.shape[0] > 0 and per_sample <= ROW_MASKS_MAX_M:
+                nan_idx[var], count = _row_masks(a, lo, hi, per_sample)      # one pass over the array (csrc/pem_masks.hip)
+            else:
+                nan_idx[var] = torch.isnan(a).any(dim=rest) if rest else torch.isnan(a)
+                outside = (a < lo) | (a > hi)
+                count = outside.sum(dim=rest) if rest else outside.long()
             outlier_idx[var] = count > int(cnt_thresh * per_sample)
         else:
             a = np.asarray(arr, dtype=np.float64)

@@ -299,6 +299,16 @@ int pem_quantiles_f64_dev(size_t n, int m, const double* data, size_t ld, int nq
                           const double* gamma, double* out, pem_stream_t stream);
 int pem_quantiles_last_path(void);
 
+/* The per-sample masks of `_filter_outputs` (scripts/gen_data.py:150-168) for one output variable in one pass over it
+ * (csrc/pem_masks.hip): data [n][ld] row-major, entries 0..m-1 of a sample; lo / hi: m per-entry bounds each (DEVICE arrays:
+ * p25 - f iqr and p75 + f iqr, computed by the caller from pem_quantiles_f64_dev's result as the reference does);
+ * nan_out[i] = 1 if sample i holds a NaN (`np.any(np.isnan(arr), axis=rest)`), outside_out[i] = the number of its entries with
+ * x < lo or x > hi (`np.sum((arr < lo) | (arr > hi), axis=rest)`; a comparison with a NaN is false, as in numpy) -- the caller
+ * compares it with int(0.75 * m).  1 <= m <= PEM_ROW_MASKS_MAX_M.  Asynchronous on `stream`.                                  */
+#define PEM_ROW_MASKS_MAX_M 512
+int pem_row_masks_f64_dev(size_t n, int m, const double* data, size_t ld, const double* lo, const double* hi, uint8_t* nan_out,
+                          int32_t* outside_out, pem_stream_t stream);
+
 /* The multi-rank building blocks of the same selection (samples sharded over GPUs; hallthrusterpem_amd/percentiles.py drives the
  * levels and all-reduces between them): per-column min / max of the order-preserving 64-bit image of the values (sign bit
  * flipped, negative values inverted; kmin > kmax: no finite-or-infinite value) and a NaN flag; and the histogram of the keys

@@ -163,6 +163,61 @@ def test_filter_outputs_on_the_device_equals_the_host_path_at_a_size_torch_quant
     assert np.array_equal(got, np.percentile(big, [25.0, 75.0]))
 
 
+@pytest.mark.parametrize('shape', [(1, 1), (1000, 1), (50_001, 3), (4_000, 64), (4_001, 65), (30_000, 91), (3_000, 129), (2_000, 256),
+                                   (1_500, 300), (700, 512), (300, 600), (5_000, 7, 13)])
+def test_filter_outputs_masks_equal_the_numpy_branch(shape):
+    """The one-pass NaN / outside-count kernel (csrc/pem_masks.hip) behind drivers.filter_outputs on CUDA tensors against the
+    numpy branch (= the reference's arithmetic, tests/test_reference_suite.py pins that one to the reference's own function):
+    every row layout of the kernel (1..64 entries: several rows per wave instruction; 65..512: 2, 4, 8 chunks per row), more
+    than 512 entries (the torch expressions), NaNs, infinities, a column whose bounds are NaN."""
+    import torch
+    from hallthrusterpem_amd.drivers import filter_outputs
+    rng = np.random.default_rng(sum(shape) + 17)
+    a = rng.lognormal(0.0, 1.0, shape)
+    n = shape[0]
+    a[rng.random(n) < 0.02] *= 1e3                           # whole samples far outside: outliers of the variable
+    a[rng.random(shape) < 0.01] = 1e4                        # single entries outside
+    if n > 10:
+        a[3].flat[0] = np.nan
+        a[n // 2].flat[-1] = np.nan
+        a[7].flat[0] = np.inf
+        a[8].flat[0] = -np.inf
+    for f in (1.5, 0.0):
+        nan_h, out_h = filter_outputs({'v': a, 'v_coords': a, 'errors': a}, iqr_factor=f)
+        nan_d, out_d = filter_outputs({'v': torch.from_numpy(a).cuda(), 'v_coords': a, 'errors': a}, iqr_factor=f)
+        assert set(nan_d) == {'v'} and nan_d['v'].dtype == torch.bool and out_d['v'].dtype == torch.bool
+        assert np.array_equal(nan_h['v'], nan_d['v'].cpu().numpy()) and np.array_equal(out_h['v'], out_d['v'].cpu().numpy())
+    if n > 10:
+        assert nan_h['v'].sum() == 2                         # (the entries that hold a NaN have NaN bounds: nothing is outside them)
+
+
+def test_row_masks_entry_point_counts_and_errors():
+    import ctypes as C
+    import torch
+    from hallthrusterpem_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(23)
+    for n, m, ld in ((777, 5, 8), (1000, 91, 96), (64, 200, 200)):
+        a = rng.standard_normal((n, ld))
+        a[::50, 0] = np.nan
+        lo, hi = rng.normal(-1.0, 0.1, m), rng.normal(1.0, 0.1, m)
+        lo[m // 2] = np.nan                                  # a comparison with NaN is false
+        d, dl, dh = (torch.from_numpy(v).cuda() for v in (a, lo, hi))
+        nan = torch.full((n,), 7, dtype=torch.uint8, device='cuda')
+        cnt = torch.full((n,), -1, dtype=torch.int32, device='cuda')
+        _lib.check(lib.pem_row_masks_f64_dev(n, m, C.c_void_p(d.data_ptr()), ld, C.c_void_p(dl.data_ptr()), C.c_void_p(dh.data_ptr()),
+                                             C.c_void_p(nan.data_ptr()), C.c_void_p(cnt.data_ptr()), None))
+        torch.cuda.synchronize()
+        with np.errstate(invalid='ignore'):
+            want = ((a[:, :m] < lo) | (a[:, :m] > hi)).sum(axis=1)
+        assert np.array_equal(cnt.cpu().numpy(), want) and np.array_equal(nan.cpu().numpy(), np.isnan(a[:, :m]).any(axis=1))
+    assert lib.pem_row_masks_f64_dev(10, 0, None, 0, None, None, None, None, None) == 1            # PEM_ERR_INVALID_ARG
+    assert lib.pem_row_masks_f64_dev(10, 513, C.c_void_p(d.data_ptr()), 513, None, None, None, None, None) == 1
+    assert lib.pem_row_masks_f64_dev(10, 4, C.c_void_p(d.data_ptr()), 3, C.c_void_p(dl.data_ptr()), C.c_void_p(dh.data_ptr()),
+                                     C.c_void_p(nan.data_ptr()), C.c_void_p(cnt.data_ptr()), None) == 1
+    assert lib.pem_row_masks_f64_dev(0, 4, None, 4, None, None, None, None, None) == 0               # nothing to do
+
+
 def test_percentile_bands_of_a_forward_uq_campaign():
     from hallthrusterpem_amd import drivers
     out = drivers.forward_uq(300_000, seed=4, keep_profile=True)

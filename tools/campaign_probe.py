@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""One forward-UQ campaign of BASELINE configs[2] on one GPU, stage by stage: sample + evaluate (drivers.forward_uq, profile kept),
+NaN / interquartile-range masks (drivers.filter_outputs = gen_data.py:125-174) and the 5 / 50 / 95 % bands
+(drivers.percentile_bands = monte_carlo.py:363-658).  Wall time per stage, best of five, results left on the device.
+    python tools/campaign_probe.py [n]"""
+import sys, time
+from pathlib import Path
+import torch
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from hallthrusterpem_amd import drivers
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+
+
+def wall(fn, reps=5):
+    fn(); torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(reps):
+        t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0); del r
+    return best
+
+
+out = drivers.forward_uq(n, seed=2, keep_profile=True)
+keep = {k: out[k] for k in ('V_cc', 'div_angle', 'T_c', 'j_ion')}
+t_model = wall(lambda: drivers.forward_uq(n, seed=2, keep_profile=True))
+t_filter = wall(lambda: drivers.filter_outputs(keep))
+t_bands = wall(lambda: drivers.percentile_bands(out))
+total = t_model + t_filter + t_bands
+print(f'forward-UQ campaign, {n} coupled samples, one MI355X (fp64, 91-point profile kept):')
+print(f'  sample + evaluate (forward_uq)          {t_model * 1e3:8.2f} ms   {n / t_model / 1e9:6.2f} G evals/s')
+print(f'  NaN / IQR masks (filter_outputs)        {t_filter * 1e3:8.2f} ms')
+print(f'  5 / 50 / 95 % bands (percentile_bands)  {t_bands * 1e3:8.2f} ms')
+print(f'  whole campaign                          {total * 1e3:8.2f} ms   {n / total / 1e9:6.2f} G evals/s')
