@@ -95,8 +95,13 @@ def _row_masks(a, lo, hi, per_sample: int):
     return nan.bool(), count
 
 
-def filter_outputs(outputs: dict, iqr_factor: float = 1.5):
+def filter_outputs(outputs: dict, iqr_factor: float = 1.5, group=None, sharded: bool | None = None):
     """NaN and interquartile-range outlier masks per output variable; mirrors gen_data.py:125-174.
+
+    sharded (default: whenever a process group of more than one rank is initialised): `outputs` is THIS rank's shard of the
+    samples; p25 / p75 are then those of ALL ranks' samples (`percentiles.column_percentiles_sharded`, or its numpy restatement
+    for numpy arrays) and the masks returned are those of the local samples -- together the masks the reference computes on
+    the whole data set.
 
     `outputs`: {name: array (num_samples, ...)} of numeric numpy arrays or torch tensors (device tensors stay on
     the device).  Names containing '_coords' and the name 'errors' are skipped.  A sample is an outlier of a
@@ -105,6 +110,9 @@ def filter_outputs(outputs: dict, iqr_factor: float = 1.5):
     Returns (nan_idx, outlier_idx): dicts of boolean arrays of shape (num_samples,)."""
     nan_idx, outlier_idx = {}, {}
     cnt_thresh = 0.75
+    if sharded is None:
+        import torch.distributed as dist
+        sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     for var, arr in outputs.items():
         if COORDS_STR_ID in str(var) or str(var) == 'errors':
             continue
@@ -113,7 +121,13 @@ def filter_outputs(outputs: dict, iqr_factor: float = 1.5):
             a = arr.double()
             rest = tuple(range(1, a.dim()))
             per_sample = int(np.prod(a.shape[1:])) if a.dim() > 1 else 1
-            q = column_percentiles(a, [25.0, 75.0]) if a.is_cuda else torch.quantile(a, torch.tensor([0.25, 0.75], dtype=a.dtype), dim=0)
+            if sharded:
+                from .percentiles import column_percentiles_numpy, column_percentiles_sharded
+                q = column_percentiles_sharded(a, [25.0, 75.0], group=group) if a.is_cuda else \
+                    column_percentiles_numpy(a.numpy(), [25.0, 75.0], group=group)
+                q = torch.from_numpy(np.ascontiguousarray(q)).to(a.device)
+            else:
+                q = column_percentiles(a, [25.0, 75.0]) if a.is_cuda else torch.quantile(a, torch.tensor([0.25, 0.75], dtype=a.dtype), dim=0)
             iqr = q[1] - q[0]
             lo, hi = q[0] - iqr_factor * iqr, q[1] + iqr_factor * iqr
             if a.is_cuda and a.shape[0] > 0 and per_sample <= ROW_MASKS_MAX_M:
@@ -127,7 +141,11 @@ def filter_outputs(outputs: dict, iqr_factor: float = 1.5):
             a = np.asarray(arr, dtype=np.float64)
             rest = tuple(range(1, a.ndim))
             nan_idx[var] = np.any(np.isnan(a), axis=rest)
-            p25, p75 = np.percentile(a, 25, axis=0), np.percentile(a, 75, axis=0)
+            if sharded:
+                from .percentiles import column_percentiles_numpy
+                p25, p75 = column_percentiles_numpy(a, [25.0, 75.0], group=group)
+            else:
+                p25, p75 = np.percentile(a, 25, axis=0), np.percentile(a, 75, axis=0)
             iqr = p75 - p25
             outside = (a < p25 - iqr_factor * iqr) | (a > p75 + iqr_factor * iqr)
             outlier_idx[var] = np.sum(outside, axis=rest) > int(cnt_thresh * np.prod(a.shape[1:]))

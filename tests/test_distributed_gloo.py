@@ -205,6 +205,39 @@ def test_sharded_percentiles_equal_numpy_on_the_union_of_the_shards(tmp_path, wo
     assert all((tmp_path / f'ok{r}').exists() for r in range(world))
 
 
+def _filter_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from hallthrusterpem_amd.drivers import filter_outputs
+        rng = np.random.default_rng(321)                         # every rank builds the same campaign and keeps its samples
+        n = 20_003
+        out = {'T_c': rng.normal(0.08, 0.01, n), 'j_ion': rng.lognormal(0.0, 1.0, (n, 91)), 'j_ion_coords': np.zeros((n, 91))}
+        out['T_c'][::500] = 5.0
+        out['j_ion'][5::2000] *= 1e4
+        out['j_ion'][7, 3] = np.nan
+        nan_all, outl_all = filter_outputs(out, sharded=False)                  # the reference's masks of the whole data set
+        edges = [0, 12_000, n] if world == 2 else [0, 0, 9_000, n]
+        lo, hi = edges[rank], edges[rank + 1]
+        for mine in ({k: v[lo:hi] for k, v in out.items()}, {k: torch.from_numpy(v[lo:hi]) for k, v in out.items()}):
+            nan_r, outl_r = filter_outputs(mine)                                   # sharded: a process group of `world` ranks is up
+            for k in nan_all:
+                assert np.array_equal(np.asarray(nan_r[k]), nan_all[k][lo:hi]) and np.array_equal(np.asarray(outl_r[k]), outl_all[k][lo:hi]), (rank, k)
+        assert outl_all['T_c'].sum() >= n // 500 and outl_all['j_ion'].sum() >= 5
+        Path(out_dir, f'ok{rank}').write_text('ok')
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_filter_outputs_gives_the_masks_of_the_whole_data_set(tmp_path, world):
+    """drivers.filter_outputs on one rank's samples of a campaign (numpy arrays and CPU tensors here; one rank without samples at
+    world 3): p25 / p75 are those of all ranks' samples, so the local masks are the slices of the masks gen_data.py:125-174
+    computes on the whole data set."""
+    mp.spawn(_filter_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f'ok{r}').exists() for r in range(world))
+
+
 def test_percentiles_of_more_columns_than_one_kernel_call_takes():
     """More than 256 columns go through the kernels 256 at a time, so the bins per level are bounded by the CHUNK's width: sized
     from the whole width (round 2) they came out as 1 for m > 3072 with three percentiles, the ranges never narrowed and the

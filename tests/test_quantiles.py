@@ -380,6 +380,15 @@ def _two_rank_worker(rank, world, port, out_dir):
         bands = drivers.percentile_bands(mine, names=('T_c', 'j_ion'))
         for k in ('T_c', 'j_ion'):
             assert bands[k].is_cuda and np.array_equal(bands[k].cpu().numpy(), np.percentile(out[k].cpu().numpy(), [5.0, 50.0, 95.0], axis=0), equal_nan=True)
+        # ... and the NaN / IQR masks of the whole campaign's data set, for this rank's samples
+        whole = {k: out[k].clone() for k in ('j_ion', 'T_c')}
+        whole['T_c'][::777] = 9.0
+        whole['j_ion'][123_456, 5] = float('nan')
+        nan_all, outl_all = drivers.filter_outputs(whole, sharded=False)
+        nan_r, outl_r = drivers.filter_outputs({k: v[lo:hi].contiguous() for k, v in whole.items()})
+        for k in nan_all:
+            assert torch.equal(nan_r[k], nan_all[k][lo:hi]) and torch.equal(outl_r[k], outl_all[k][lo:hi]), (rank, k)
+        assert int(outl_all['T_c'].sum()) >= n // 777 and int(nan_all['j_ion'].sum()) == 1
         open(os.path.join(out_dir, f'ok{rank}'), 'w').write('ok')
     finally:
         dist.destroy_process_group()
