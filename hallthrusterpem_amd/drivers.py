@@ -52,20 +52,20 @@ def column_percentiles(a, percentiles):
     if not flat.is_contiguous():
         flat = flat.contiguous()
     m = flat.shape[1]
-    order = np.arange(q.size)                               # three quantiles per launch
     out = torch.empty((q.size, m), dtype=torch.float64, device=flat.device)
     lib = _lib.load()
     stream = C.c_void_p(torch.cuda.current_stream(flat.device).cuda_stream)
     with torch.cuda.device(flat.device):
-        for c0 in range(0, m, 256):
+        for c0 in range(0, m, 256):                         # 256 columns and three quantiles per call
             mc = min(256, m - c0)
             for i0 in range(0, q.size, 3):
-                idx = order[i0:i0 + 3]
-                rp, rn, gm = (np.ascontiguousarray(v[idx]) for v in (rank_prev, rank_next, gamma))
-                part = torch.empty((idx.size, mc), dtype=torch.float64, device=flat.device)
-                _lib.check(lib.pem_quantiles_f64_dev(n, mc, C.c_void_p(flat.data_ptr() + 8 * c0), m, idx.size, C.c_void_p(rp.ctypes.data),
+                rp, rn, gm = (np.ascontiguousarray(v[i0:i0 + 3]) for v in (rank_prev, rank_next, gamma))
+                # the call writes rows of mc values: straight into `out` when that is all of its columns
+                part = out[i0:i0 + rp.size] if mc == m else torch.empty((rp.size, mc), dtype=torch.float64, device=flat.device)
+                _lib.check(lib.pem_quantiles_f64_dev(n, mc, C.c_void_p(flat.data_ptr() + 8 * c0), m, rp.size, C.c_void_p(rp.ctypes.data),
                                                      C.c_void_p(rn.ctypes.data), C.c_void_p(gm.ctypes.data), C.c_void_p(part.data_ptr()), stream))
-                out[torch.from_numpy(idx).to(flat.device), c0:c0 + mc] = part
+                if mc != m:
+                    out[i0:i0 + rp.size, c0:c0 + mc] = part
     out = out.reshape((q.size,) + tuple(a.shape[1:]))
     return out[0] if scalar else out
 
