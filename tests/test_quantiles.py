@@ -66,7 +66,8 @@ def pilot_from(monkeypatch):
     return set_min
 
 
-@pytest.mark.parametrize('shape', [(129, 1), (4_000, 64), (4_000, 65), (40_000, 91), (3_000, 129), (2_000, 256), (600_000, 91), (2_000_000, 3)])
+@pytest.mark.parametrize('shape', [(129, 1), (4_000, 64), (4_000, 65), (40_000, 91), (3_000, 129), (2_000, 256), (1_500, 300), (20_000, 7, 13),
+                                   (600_000, 91), (2_000_000, 3)])
 def test_pilot_form_equals_numpy(shape, pilot_from):
     pilot_from(128)
     rng = np.random.default_rng(sum(shape) + 1)
