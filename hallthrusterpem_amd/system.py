@@ -91,7 +91,7 @@ class PemV0System:
     components = ('Cathode', 'Thruster (analytic test double)', 'Plume')
 
     def __init__(self, root_dir=None, name: str = 'PEM_v0_SPT-100', priors=None, seed: int = 0, sweep_radius: float = 1.0):
-        self.name, self.root_dir = name, (Path(root_dir) if root_dir is not None else None)
+        self.name, self.root_dir = name, root_dir
         self.priors = dict(PEM_V0_PRIORS if priors is None else priors)
         self.sweep_radius = float(sweep_radius)
         self._inputs = VariableList(Variable(k, CATEGORY.get(k, 'calibration'), self.priors[k], NORM.get(k))
@@ -105,6 +105,18 @@ class PemV0System:
         self.surrogate = None
         self.train_history = []
         self.logger = logging.getLogger(name)
+
+    @property
+    def root_dir(self):
+        return self._root_dir
+
+    @root_dir.setter
+    def root_dir(self, value):
+        """Setting the root directory creates it, as amisc's `System.root_dir` does: gen_data.py:442-446 lists it right after
+        assigning it and fit_surr.py:149 moves a system into a sub-directory that does not exist yet."""
+        self._root_dir = Path(value) if value is not None else None
+        if self._root_dir is not None:
+            self._root_dir.mkdir(parents=True, exist_ok=True)
 
     # ------------------------------------------------------------------------------------------------ bookkeeping
     def inputs(self):

@@ -25,6 +25,19 @@ def test_variable_is_name_like_and_normalises():
     assert coords == {} and phys['c4'][0] == 1e20 and np.isclose(phys['Pstar'][0], 2e-5) and phys['other'] == 3
 
 
+def test_setting_the_root_directory_creates_it(tmp_path):
+    """amisc's `System.root_dir` setter creates the directory: gen_data.py:442-446 lists it right after assigning it and
+    fit_surr.py:149 moves the system into a sub-directory that does not exist yet (README's first snippet relies on it)."""
+    from hallthrusterpem_amd.system import PemV0System
+    system = PemV0System(root_dir=tmp_path / 'run' / 'a')
+    assert system.root_dir == tmp_path / 'run' / 'a' and system.root_dir.is_dir()
+    system.root_dir = system.root_dir / 'amisc_single_fidelity'
+    assert system.root_dir.is_dir() and system.root_dir.name == 'amisc_single_fidelity'
+    system.root_dir = str(tmp_path / 'run')                       # an existing directory, given as a string
+    assert system.root_dir == tmp_path / 'run'
+    assert PemV0System().root_dir is None
+
+
 @pytest.mark.gpu
 def test_sample_inputs_follow_the_variable_table():
     from hallthrusterpem_amd.system import PemV0System
@@ -106,3 +119,18 @@ def test_fit_trains_a_surrogate_and_predict_switches_to_it():
     assert evals.shape == (8,) and evals.sum() == hist[-1]['model_evals'] and overhead == 0.0
     system.clear()
     assert system.surrogate is None and system.train_history == []
+
+
+@pytest.mark.gpu
+def test_the_python_snippet_of_the_readme_runs(tmp_path, monkeypatch):
+    """What a new user pastes first (README.md): the three drop-in calls and `generate_data` on a system whose root directory
+    does not exist yet."""
+    from pathlib import Path
+    text = (Path(__file__).resolve().parents[1] / 'README.md').read_text()
+    start = text.index('```python') + len('```python')
+    code = text[start:text.index('```', start)]
+    monkeypatch.chdir(tmp_path)
+    ns = {}
+    exec(compile(code, 'README.md', 'exec'), ns)
+    assert 25.0 < float(ns['v'][0]) < 35.0 and len(ns['s']['inputs']) == 12
+    assert set(ns['data']) == {'compression', 'nan_idx', 'outlier_idx', 'iqr_factor'} and (tmp_path / 'run' / 'compression' / 'compression.pkl').exists()
