@@ -1,0 +1,62 @@
+"""INTEGRATION.md section 2 shows the ctypes binding a maintainer of the reference would add (`src/hallmd/models/_pem_hip.py`).
+The block is executed here as it stands in the document -- with `pem_core.constants` supplied (the package is absent from this
+image) and the library's name resolved to the in-tree build -- and held to the package's own wrappers and the oracle."""
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _stub_namespace():
+    text = (ROOT / 'INTEGRATION.md').read_text()
+    start = text.index('# src/hallmd/models/_pem_hip.py')
+    code = text[start:text.index('```', start)]
+    assert 'C.CDLL("libpem_hip.so")' in code
+    code = code.replace('C.CDLL("libpem_hip.so")', f'C.CDLL({str(ROOT / "hallthrusterpem_amd" / "libpem_hip.so")!r})')
+    const = types.ModuleType('pem_core.constants')
+    const.TORR_2_PA = 133.322
+    pkg = types.ModuleType('pem_core')
+    pkg.constants = const
+    keep = {k: sys.modules.get(k) for k in ('pem_core', 'pem_core.constants')}
+    sys.modules.update({'pem_core': pkg, 'pem_core.constants': const})
+    try:
+        ns = {}
+        exec(compile(code, 'INTEGRATION.md', 'exec'), ns)
+    finally:
+        for k, v in keep.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    return ns
+
+
+@pytest.mark.gpu
+def test_the_binding_of_integration_md_gives_the_wrappers_results():
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / 'tests'))
+    from _inputs import cathode_inputs, plume_inputs
+    from oracle import oracle_ctypes as oc
+    from hallthrusterpem_amd import _lib
+    from hallthrusterpem_amd.models import cathode_coupling, current_density
+    _lib.load()                                              # (the process's HIP runtime is the one torch brought)
+    stub = _stub_namespace()
+    c = cathode_inputs(5000, seed=3)
+    got = stub['cathode_coupling'](c)
+    assert set(got) == {'V_cc'} and np.array_equal(got['V_cc'], cathode_coupling(c)['V_cc'])
+    assert np.allclose(got['V_cc'], oc.cathode(*(c[k] for k in ('P_b', 'V_a', 'T_e', 'V_vac', 'Pstar', 'P_T')), 133.322), rtol=1e-12, atol=0)
+    scalar = stub['cathode_coupling']({'P_b': 1e-5, 'V_a': 300, 'T_e': 3, 'V_vac': 30, 'Pstar': 2e-5, 'P_T': 5e-5})
+    assert scalar['V_cc'].shape == (1,) and abs(scalar['V_cc'][0] - 30.118393) < 1e-5
+    p = plume_inputs(3000, seed=4)
+    for radius in (1.0, np.array([0.5, 1.0, 1.5])):
+        got, want = stub['current_density'](p, sweep_radius=radius), current_density(p, sweep_radius=radius)
+        assert set(got) == set(want)
+        for k in ('j_ion', 'div_angle', 'T_c'):
+            assert got[k].shape == want[k].shape and np.array_equal(got[k], want[k], equal_nan=True), (k, radius)
+        assert got['j_ion_coords'].shape == want['j_ion_coords'].shape and np.array_equal(got['j_ion_coords'].flat[0], want['j_ion_coords'].flat[0])
+    no_t = {k: v for k, v in p.items() if k != 'T'}
+    assert 'T_c' not in stub['current_density'](no_t)
