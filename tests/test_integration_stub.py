@@ -60,3 +60,19 @@ def test_the_binding_of_integration_md_gives_the_wrappers_results():
         assert got['j_ion_coords'].shape == want['j_ion_coords'].shape and np.array_equal(got['j_ion_coords'].flat[0], want['j_ion_coords'].flat[0])
     no_t = {k: v for k, v in p.items() if k != 'T'}
     assert 'T_c' not in stub['current_density'](no_t)
+
+
+@pytest.mark.gpu
+def test_the_driver_flow_of_integration_md_runs(tmp_path, monkeypatch):
+    """Section 3a: gen_data.py's and fit_surr.py's calls on `PemV0System`, executed as the document shows them."""
+    text = (ROOT / 'INTEGRATION.md').read_text()
+    start = text.index("system = PemV0System(root_dir='pem_v0_run')")
+    start = text.rindex('```python', 0, start) + len('```python')
+    code = text[start:text.index('```', start)]
+    sys.path.insert(0, str(ROOT))
+    monkeypatch.chdir(tmp_path)
+    ns = {}
+    exec(compile(code, 'INTEGRATION.md', 'exec'), ns)
+    assert (tmp_path / 'pem_v0_run' / 'compression' / 'compression.pkl').exists() and (tmp_path / 'pem_v0_run' / 'test_set' / 'test_set.pkl').exists()
+    assert set(ns['y']) >= {'V_cc', 'div_angle'} and np.shape(ns['y']['V_cc']) == (1000,) and np.all(np.isfinite(np.asarray(ns['y']['V_cc'])))
+    assert ns['model_evals'] is not None and ns['system'].surrogate is not None
