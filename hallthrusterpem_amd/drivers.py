@@ -162,13 +162,16 @@ def discard_mask(nan_idx: dict, outlier_idx: dict, discard_outliers: bool = Fals
 
 
 # ------------------------------------------------------------------------------------------- forward evaluation loops
-def forward_uq(n: int, seed: int = 0, method: str = 'mc', profile: bool = False, batch_size: int = 1 << 21,
+def forward_uq(n: int, seed: int = 0, method: str = 'mc', profile: bool = False, batch_size: int | None = None,
                priors=None, device=None, keep_profile: bool = False, rank: int = 0, world: int = 1, streams: int = 1):
     """Forward propagation of the PEM-v0 priors through cathode -> thruster (test double) -> plume.
 
     Draws global samples [0, n) of the counter-based design (this rank evaluates its contiguous shard), evaluates
-    them in batches of `batch_size` and returns per-sample QoIs of the shard as CUDA tensors:
+    them and returns per-sample QoIs of the shard as CUDA tensors:
     `V_cc, div_angle, T_c, I_B0, T, invalid`, the inputs `x` ([15][n_local]) and, if `keep_profile`, `j_ion`.
+    `batch_size` (default: the whole shard in ONE launch; 1e7 samples with the profile: 1.51 ms against 1.61 in launches of 2^21
+    and 1.80 of 2^20, without it 0.66 / 0.70 / 0.77 -- every launch pays its own ramp and tail, tools/forward_uq_batch_probe.py)
+    cuts the shard into launches over ranges of the resident batch, e.g. to interleave other work on the stream.
     `streams` > 1 deals the launches of a shard of several batches onto that many side streams (they write disjoint ranges; the side
     streams begin after, and the caller's stream continues after, everything enqueued here).  It is NOT the default: what gains
     3-7 % for the evaluate-only launches of bench.py loses 8-20 % here (1e7 samples: 1.77 -> 1.92 ms with the profile, 0.71 -> 0.86 ms
@@ -181,7 +184,8 @@ def forward_uq(n: int, seed: int = 0, method: str = 'mc', profile: bool = False,
     # ONE resident batch holds the shard's inputs and outputs; the launches write ranges of it in place (a scratch batch
     # plus per-batch copies into the result arrays cost more HBM traffic than the reduced-QoI kernel itself)
     batch = CoupledBatch(n_local, device=device, profile=profile or keep_profile)
-    bs = max(64, min(int(batch_size), n_local)) & ~1          # ranges start at even samples (16-byte aligned profile rows)
+    bs = n_local if batch_size is None else max(64, min(int(batch_size), n_local)) & ~1   # ranges start at even samples (16-byte aligned profile rows)
+    bs = max(bs, 1)
     caller = torch.cuda.current_stream(batch.device)
     side = None
     if streams > 1 and n_local > bs:
@@ -284,7 +288,7 @@ def process_compression(system, data: dict, discard_outliers: bool = False):
 
 
 def generate_data_on_device(n: int, seed: int = 0, description: str = 'test_set', method: str = 'mc',
-                            iqr_factor: float = 1.5, batch_size: int = 1 << 20, device=None):
+                            iqr_factor: float = 1.5, batch_size: int | None = None, device=None):
     """`generate_data` without the system object, batched (fused sampling + evaluation kernel, any n): returns the
     same dictionary layout with CUDA tensors."""
     import torch

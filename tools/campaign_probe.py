@@ -12,8 +12,13 @@ from hallthrusterpem_amd import drivers
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 
 
-def wall(fn, reps=5):
-    fn(); torch.cuda.synchronize()
+def wall(fn, reps=7, warm_ms=40.0):
+    """best wall time of `reps` calls, after calls for `warm_ms` (the clocks ramp for ~15 ms after an idle period: profiles/warmup_r03.txt)"""
+    t0 = time.perf_counter()
+    while True:
+        r = fn(); torch.cuda.synchronize(); del r
+        if time.perf_counter() - t0 >= 1e-3 * warm_ms:
+            break
     best = 1e9
     for _ in range(reps):
         t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0); del r
