@@ -38,6 +38,8 @@ Prints ONE JSON line on rank 0 with the fields the driver expects plus
                   NumPy rate from BASELINE.md (measured in the build container, not on this host) beside it;
   config.full_config (N = 1): the whole 1e7-sample configs[2] campaign as ONE launch on this GPU, measured in the
                   same run (8.7 GB of algorithmic traffic per pass).
+  config.campaign (N = 1): the sampling loop around the hot path at configs[2] size, stage by stage -- sample + evaluate,
+                  NaN / IQR masks, 5 / 50 / 95 % bands (outside the timed region).
   --fp32 adds the config-5 report: the fp32-arithmetic reduced-QoI kernel against the fp64 one on identical inputs.
 """
 import argparse
@@ -201,6 +203,46 @@ def full_config_pass(n, seed, lanes, layout='soa'):
     return rec
 
 
+def campaign_report(n, seed):
+    """One forward-UQ campaign of `n` samples on this GPU, stage by stage (N = 1 only, outside the timed region): the sampling
+    loop around the hot path -- sample + evaluate with the profile kept (drivers.forward_uq), the NaN / IQR masks of
+    gen_data.py:125-174 (drivers.filter_outputs) and the 5 / 50 / 95 % bands of monte_carlo.py:363-658
+    (drivers.percentile_bands).  Best wall time of three calls after one, results on the device.  Never lets the line down: an
+    exception is reported in its place."""
+    import torch
+    try:
+        from hallthrusterpem_amd import drivers
+
+        def best(fn, reps=3):
+            r = fn()
+            torch.cuda.synchronize()
+            del r
+            t_best = 1e9
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                r = fn()
+                torch.cuda.synchronize()
+                t_best = min(t_best, time.perf_counter() - t0)
+                del r
+            return t_best
+
+        t_model = best(lambda: drivers.forward_uq(n, seed=seed, keep_profile=True))
+        out = drivers.forward_uq(n, seed=seed, keep_profile=True)
+        keep = {k: out[k] for k in ('V_cc', 'div_angle', 'T_c', 'j_ion')}
+        t_masks = best(lambda: drivers.filter_outputs(keep))
+        t_bands = best(lambda: drivers.percentile_bands(out))
+        total = t_model + t_masks + t_bands
+        rec = {'samples': n, 'forward_uq_ms': 1e3 * t_model, 'filter_outputs_ms': 1e3 * t_masks, 'percentile_bands_ms': 1e3 * t_bands,
+               'total_ms': 1e3 * total, 'samples_per_s': n / total,
+               'note': 'sample + evaluate (profile kept), NaN / IQR masks, 5/50/95 % bands of every output; wall time per stage, '
+                       'best of three; exact percentiles (equal to numpy bit for bit)'}
+        del out, keep
+        torch.cuda.empty_cache()
+        return rec
+    except Exception as exc:                              # (reported, not raised: the headline line must not depend on this leg)
+        return {'samples': n, 'error': f'{type(exc).__name__}: {exc}'}
+
+
 def fp32_report(n, seed):
     """config 5's tolerance check: the fp32-arithmetic reduced-QoI kernel against the fp64 one on identical inputs."""
     from hallthrusterpem_amd.fp32 import compare_with_fp64
@@ -263,6 +305,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--full-config-samples', type=int, default=FULL_CONFIG_SAMPLES,
                     help='N=1: also run the whole configs[2] campaign as one launch of this many samples (0 = skip)')
+    ap.add_argument('--campaign-samples', type=int, default=FULL_CONFIG_SAMPLES,
+                    help='N=1: also time one forward-UQ campaign of this many samples stage by stage -- sample + evaluate, NaN / IQR '
+                         'masks, 5/50/95 %% bands (config.campaign; 0 = skip)')
     ap.add_argument('--seed', type=int, default=2)
     ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL; default) or gloo (rehearsal on one GPU)')
     ap.add_argument('--oversubscribe', action='store_true',
@@ -562,6 +607,8 @@ def main():
             del batch, batches, b
             torch.cuda.empty_cache()
             line['config']['full_config'] = full_config_pass(args.full_config_samples, args.seed, lanes, args.layout)
+        if world == 1 and not multi and args.campaign_samples > 0 and not (args.no_profile or args.mixed):
+            line['config']['campaign'] = campaign_report(args.campaign_samples, args.seed)
         if args.fp32 and world == 1:
             line['fp32'] = fp32_report(n, args.seed)
         if world == 1 and not args.no_cpu_baseline:

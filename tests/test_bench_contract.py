@@ -14,7 +14,7 @@ ROOT = Path(__file__).resolve().parents[1]
 pytestmark = pytest.mark.gpu
 KEYS = {'metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
         'dtype', 'data', 'config', 'roofline', 'cpu_baseline'}
-SMALL = ['--steps', '4', '--warmup', '2', '--samples-per-gpu', '131072', '--full-config-samples', '0']
+SMALL = ['--steps', '4', '--warmup', '2', '--samples-per-gpu', '131072', '--full-config-samples', '0', '--campaign-samples', '0']
 
 
 def _one_json_line(stdout: str) -> dict:
@@ -67,10 +67,13 @@ def test_single_stream_and_soa_inputs_are_options():
 def test_single_gpu_line_carries_the_whole_config():
     """configs[2] is 1e7 coupled samples: at N = 1 the line also carries that campaign as one launch, measured in the same
     run (here at a reduced size so that the test stays short; the driver's run uses the default 1e7)."""
-    out = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--steps', '4', '--warmup', '2', '--full-config-samples', '2000000'],
-                         capture_output=True, text=True, cwd=ROOT, timeout=600)
+    out = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--steps', '4', '--warmup', '2', '--full-config-samples', '2000000',
+                          '--campaign-samples', '300000'], capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = _one_json_line(out.stdout)
+    camp = line['config']['campaign']                       # the sampling loop around the hot path, stage by stage
+    assert 'error' not in camp and camp['samples'] == 300_000 and camp['samples_per_s'] > 1e6
+    assert abs(camp['total_ms'] - (camp['forward_uq_ms'] + camp['filter_outputs_ms'] + camp['percentile_bands_ms'])) < 1e-9
     fc = line['config']['full_config']
     assert fc['samples'] == 2_000_000 and fc['bytes_per_launch'] == 872 * 2_000_000 and fc['value'] > 1e9
     assert abs(fc['frac_of_peak'] - fc['achieved_GBs'] / 8000.0) < 1e-12 and 0.3 < fc['frac_of_peak'] < 1.0
