@@ -207,16 +207,20 @@ def campaign_report(n, seed):
     """One forward-UQ campaign of `n` samples on this GPU, stage by stage (N = 1 only, outside the timed region): the sampling
     loop around the hot path -- sample + evaluate with the profile kept (drivers.forward_uq), the NaN / IQR masks of
     gen_data.py:125-174 (drivers.filter_outputs) and the 5 / 50 / 95 % bands of monte_carlo.py:363-658
-    (drivers.percentile_bands).  Best wall time of three calls after one, results on the device.  Never lets the line down: an
+    (drivers.percentile_bands).  Best wall time of three calls after 30 ms of the same calls, results on the device.  Never lets the line down: an
     exception is reported in its place."""
     import torch
     try:
         from hallthrusterpem_amd import drivers
 
-        def best(fn, reps=3):
-            r = fn()
-            torch.cuda.synchronize()
-            del r
+        def best(fn, reps=3, warm_ms=30.0):
+            t_warm = time.perf_counter()                  # (allocating the stage's buffers idles the GPU: clocks ramp again, see --spin-up-ms)
+            while True:
+                r = fn()
+                torch.cuda.synchronize()
+                del r
+                if time.perf_counter() - t_warm >= 1e-3 * warm_ms:
+                    break
             t_best = 1e9
             for _ in range(reps):
                 t0 = time.perf_counter()
