@@ -163,7 +163,8 @@ def discard_mask(nan_idx: dict, outlier_idx: dict, discard_outliers: bool = Fals
 
 # ------------------------------------------------------------------------------------------- forward evaluation loops
 def forward_uq(n: int, seed: int = 0, method: str = 'mc', profile: bool = False, batch_size: int | None = None,
-               priors=None, device=None, keep_profile: bool = False, rank: int = 0, world: int = 1, streams: int = 1):
+               priors=None, device=None, keep_profile: bool = False, rank: int = 0, world: int = 1, streams: int = 1,
+               keep_inputs: bool = True):
     """Forward propagation of the PEM-v0 priors through cathode -> thruster (test double) -> plume.
 
     Draws global samples [0, n) of the counter-based design (this rank evaluates its contiguous shard), evaluates
@@ -172,6 +173,8 @@ def forward_uq(n: int, seed: int = 0, method: str = 'mc', profile: bool = False,
     `batch_size` (default: the whole shard in ONE launch; 1e7 samples with the profile: 1.51 ms against 1.61 in launches of 2^21
     and 1.80 of 2^20, without it 0.66 / 0.70 / 0.77 -- every launch pays its own ramp and tail, tools/forward_uq_batch_probe.py)
     cuts the shard into launches over ranges of the resident batch, e.g. to interleave other work on the stream.
+    `keep_inputs=False` (method 'mc' only): the generated inputs are not written out and `x` is left out of the result -- a
+    campaign that only looks at the outputs saves the 120 bytes per sample (1e7 samples: 1.54 -> 1.44 ms with the profile, 0.64 -> 0.58 without).
     `streams` > 1 deals the launches of a shard of several batches onto that many side streams (they write disjoint ranges; the side
     streams begin after, and the caller's stream continues after, everything enqueued here).  It is NOT the default: what gains
     3-7 % for the evaluate-only launches of bench.py loses 8-20 % here (1e7 samples: 1.77 -> 1.92 ms with the profile, 0.71 -> 0.86 ms
@@ -197,7 +200,7 @@ def forward_uq(n: int, seed: int = 0, method: str = 'mc', profile: bool = False,
         m = min(bs, n_local - off)
         st = side[i % len(side)] if side else caller
         if method == 'mc':      # fused: the inputs are generated inside the evaluation kernel (and stored for `x`)
-            batch.run_mc(design, first_index=lo + off, write_inputs=True, first=off, count=m, stream=st)
+            batch.run_mc(design, first_index=lo + off, write_inputs=keep_inputs, first=off, count=m, stream=st)
         else:
             design.fill(batch.inputs[:, off:off + m], first_index=lo + off, method=method, n_total=n, stream=st)
             batch.run(first=off, count=m, stream=st)
@@ -205,7 +208,9 @@ def forward_uq(n: int, seed: int = 0, method: str = 'mc', profile: bool = False,
         for st in side:
             caller.wait_event(st.record_event())
     out = {k: batch.qoi[i] for i, k in enumerate(QOI_NAMES)}
-    out.update(I_B0=batch.I_B0, T=batch.T, invalid=batch.invalid.bool(), x=batch.inputs)
+    out.update(I_B0=batch.I_B0, T=batch.T, invalid=batch.invalid.bool())
+    if keep_inputs or method != 'mc':
+        out['x'] = batch.inputs
     if keep_profile:
         out['j_ion'] = batch.j_ion
     return out

@@ -57,6 +57,8 @@ def test_forward_uq_matches_oracle_on_device_design():
     l1 = drivers.forward_uq(20_000, seed=3, method='lhs', batch_size=4096)
     assert torch.equal(l1['x'], l2['x']) and torch.equal(l1['T_c'], l2['T_c'])
     # the design does not depend on batching or sharding
+    quiet = drivers.forward_uq(n, seed=11, keep_profile=True, keep_inputs=False)       # one launch, the inputs never written
+    assert 'x' not in quiet and all(torch.equal(quiet[k], res[k]) for k in quiet)
     whole = drivers.forward_uq(n, seed=11, batch_size=1 << 20)
     other = drivers.forward_uq(n, seed=11, batch_size=7_777)
     assert torch.equal(whole['x'], res['x']) and torch.equal(whole['T_c'], other['T_c'])

@@ -26,3 +26,6 @@ for keep in (True, False):
     for bs in (n, 1 << 22, 1 << 21, 1 << 20, n):
         t = wall(lambda: drivers.forward_uq(n, seed=2, keep_profile=keep, batch_size=bs))
         print(f'forward_uq n={n} keep_profile={keep} batch_size={bs:>9}: {t * 1e3:7.3f} ms = {n / t / 1e9:5.2f} G evals/s', flush=True)
+for keep in (True, False):
+    t = wall(lambda: drivers.forward_uq(n, seed=2, keep_profile=keep, keep_inputs=False))
+    print(f'forward_uq n={n} keep_profile={keep} one launch, keep_inputs=False: {t * 1e3:7.3f} ms = {n / t / 1e9:5.2f} G evals/s', flush=True)
