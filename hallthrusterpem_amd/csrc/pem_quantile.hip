@@ -479,8 +479,10 @@ __device__ void block_sort(u64* s, int np2) {      // bitonic, np2 a power of tw
 // x_(rank) of the keys list(0) .. list(len - 1) that lie in [0, top], by one workgroup: sorted in LDS when they fit, narrowed
 // by 1024-bin histograms over the list itself until they do (heavy ties) or one key is left.  `list` is any accessor: the
 // contiguous candidate list of the single-GPU path, or the padded per-rank pieces of the sharded one (padding = ~0 > top).
+// (`short_list`, when given: set if the keys gathered for the sort are not as many as were counted a moment earlier -- a
+// slot allocation lost, as the copy pass of the pilot form once did; the caller refuses the result.)
 template <class List>
-__device__ u64 select_from(const List& list, u64 len, u64 rank, u64 top) {
+__device__ u64 select_from(const List& list, u64 len, u64 rank, u64 top, int* short_list = nullptr) {
     __shared__ u64 keys[SORT_CAP];
     __shared__ unsigned hist[1024];
     __shared__ u64 s_lo, s_hi, s_cnt, s_rank;
@@ -525,6 +527,7 @@ __device__ u64 select_from(const List& list, u64 len, u64 rank, u64 top) {
                 if (k >= lo && k <= hi) keys[atomicAdd(&s_cnt, 1ull)] = k;
             }
             __syncthreads();
+            if (short_list && threadIdx.x == 0 && s_cnt != inside) atomicExch(short_list, 1);
             block_sort(keys, np2);
             const u64 r = keys[rank < inside ? rank : inside - 1];
             __syncthreads();
@@ -592,7 +595,7 @@ __global__ __launch_bounds__(QBLOCK) void select_kernel(int nt, Target* __restri
         note[2] = T.count;
     }
     const u64* list = cand + T.offset;
-    const u64 answer = select_from([list](u64 i) { return list[i]; }, T.count, T.rank, ~0ull);
+    const u64 answer = select_from([list](u64 i) { return list[i]; }, T.count, T.rank, ~0ull, incomplete);
     if (threadIdx.x == 0) {
         T.answer = answer;
         T.done = 1;
@@ -1174,6 +1177,8 @@ extern "C" int pem_quantiles_f64_dev(size_t n, int m, const double* data, size_t
     u64 h_incomplete[4] = {0, 0, 0, 0};
     Q_TRY(hipMemcpyAsync(h_incomplete, incomplete, sizeof h_incomplete, hipMemcpyDeviceToHost, st));
     Q_TRY(hipStreamSynchronize(st));
+    if ((h_incomplete[0] & 0xffffffffull) && h_incomplete[2] == h_incomplete[3])
+        return pem::fail(PEM_ERR_HIP, "pem_quantiles: a candidate list was sorted with fewer keys than it holds (internal error; result discarded; path %d)", path);
     if (h_incomplete[0] & 0xffffffffull)
         return pem::fail(PEM_ERR_HIP,
                          "pem_quantiles: the list of column %llu, rank %llu holds %llu values where %llu were counted (internal error; result "
