@@ -583,8 +583,9 @@ __device__ u64 select_from(const List& list, u64 len, u64 rank, u64 top, int* sh
 
 // (`incomplete`: a list whose copy pass delivered another number of values than the histogram counted -- the two passes bin
 // the same way, so this says the code is wrong, not the data; the host refuses the result.  It has happened: a version of
-// compact_bracket_kernel that parked its hits in LDS lost one value in a few thousand, and more with hipcc's atomic optimizer
-// aggregating the slot counter -- which showed as percentiles one rank off, in some runs.)
+// compact_bracket_kernel that parked its hits in LDS lost one value in a few thousand -- percentiles one rank off, in some runs;
+// the cause was not found (the parking pattern alone does not lose anything: tools/microbench/lds_slot_alloc.hip) and the
+// parking, no faster than appending on the spot, was dropped.)
 __global__ __launch_bounds__(QBLOCK) void select_kernel(int nt, Target* __restrict__ tg, const u64* __restrict__ cand, int* __restrict__ incomplete) {
     Target& T = tg[blockIdx.x];
     if (T.done) return;
