@@ -1318,6 +1318,31 @@ __device__ __forceinline__ Scale column_scale(u64 kmin, u64 kmax, int bins1) {  
     return sc;
 }
 
+// The keys of bin b (bins2 = 1, g = b) or of sub-bin (b, sb) (g = b bins2 + sb) of a column's binning, [klo, khi], by bisection on
+// the monotone map d -> bin(d) bins2 + sub-bin(d).  The streaming passes test a value's HIGH word against these ranges (two 32-bit
+// instructions per wanted bin) before they bin it in full: a value outside every wanted bin -- all but a few per cent -- costs
+// neither the 64-bit subtraction nor the quarter-rate multiply of bin_of.  An empty bin comes out as klo > khi.
+__device__ __forceinline__ void keys_of_bin(const Scale& sc, u64 kmax, int bins2, long long g, u64& klo, u64& khi) {
+    const u64 D = kmax >= sc.lo ? (kmax - sc.lo) >> sc.shift : 0;
+    auto first = [&](long long G) {
+        u64 lo = 0, hi = D + 1;
+        while (lo < hi) {
+            const u64 mid = (lo + hi) >> 1, prod = mid * sc.mult;
+            const long long gd = (long long)(prod >> 32) * bins2 + (bins2 > 1 ? (long long)__umulhi((unsigned)prod, (unsigned)bins2) : 0);
+            if (gd >= G) hi = mid;
+            else lo = mid + 1;
+        }
+        return lo;
+    };
+    const u64 d0 = first(g), d1 = first(g + 1);
+    klo = sc.lo + (d0 << sc.shift);
+    khi = d1 > D ? kmax : sc.lo + (d1 << sc.shift) - 1;
+    if (d0 > D || d0 >= d1) {
+        klo = ~0ull;
+        khi = 0ull;
+    }
+}
+
 __global__ void qsel_init_kernel(int m, u64* kmin, u64* kmax, int* has_nan) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < m) {
@@ -1449,6 +1474,8 @@ __global__ __launch_bounds__(QBLOCK) void qsel_hist2_kernel(long long n, int m, 
             tb[j][t] = b;
         }
     }
+    // (no high-word test in front of the binning here, as the copy pass has: a first-level bin around the median holds 5-10 % of a
+    // column, so nearly every wave instruction has a lane inside one and the test only adds to the work: 1972 -> 2255 us for 1e7 x 91)
     stream_values<NC>(n, m, ld, data, L, [&](int j, int c, double x) {
         if (x == x) {
             unsigned frac;
@@ -1501,9 +1528,25 @@ __global__ __launch_bounds__(QBLOCK) void qsel_compact_kernel(long long n, int m
                                                                const u64* __restrict__ kmax, const int* __restrict__ bin1, const int* __restrict__ bin2,
                                                                const int* __restrict__ done, int bins1, int bins2, unsigned list_len,
                                                                u64* __restrict__ cand, unsigned* __restrict__ cursor) {
+    // the key range of every collected (bin, sub-bin), found once per workgroup -- thread i bisects for list i -- and shared
+    // through LDS: done by every lane for its own columns, the bisections were a quarter of a 1.25e6-row shard's pass
+    __shared__ unsigned s_rloh[64 * MAX_NC * 2 * PEM_QUANTILE_MAX_Q], s_rwords[64 * MAX_NC * 2 * PEM_QUANTILE_MAX_Q];
+    for (int i = threadIdx.x; i < m * NT; i += QBLOCK) {
+        const int c = i / NT, t = i - c * NT;
+        bool own = !done[i];
+        for (int u = 0; u < t; ++u)
+            if (own && !done[c * NT + u] && bin1[c * NT + u] == bin1[i] && bin2[c * NT + u] == bin2[i]) own = false;
+        u64 klo = ~0ull, khi = 0ull;
+        if (own) keys_of_bin(column_scale(kmin[c], kmax[c], bins1), kmax[c], bins2, (long long)bin1[i] * bins2 + bin2[i], klo, khi);
+        if (klo > khi) klo = khi = ~0ull;                       // nothing to collect: a range no value's key lies in
+        s_rloh[i] = (unsigned)(klo >> 32);
+        s_rwords[i] = (unsigned)(khi >> 32) - (unsigned)(klo >> 32);
+    }
+    __syncthreads();
     const Lanes L(m, threadIdx.x & 63);
     Scale sc[NC];
     int tb1[NC][NT], tb2[NC][NT];
+    unsigned rloh[NC][NT], rwords[NC][NT];                  // high words of the collected sub-bins' key ranges
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
         const int c = L.col0 + 64 * j;
@@ -1517,10 +1560,16 @@ __global__ __launch_bounds__(QBLOCK) void qsel_compact_kernel(long long n, int m
                 if (own && !done[c * NT + u] && bin1[c * NT + u] == bin1[c * NT + t] && bin2[c * NT + u] == bin2[c * NT + t]) own = false;
             tb1[j][t] = own ? bin1[c * NT + t] : -1;
             tb2[j][t] = own ? bin2[c * NT + t] : -1;
+            rloh[j][t] = on ? s_rloh[c * NT + t] : 0xffffffffu;
+            rwords[j][t] = on ? s_rwords[c * NT + t] : 0u;
         }
     }
     stream_values<NC>(n, m, ld, data, L, [&](int j, int c, double x) {
-        if (x == x) {
+        const unsigned kh = key_high(x);
+        bool near = false;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) near |= kh - rloh[j][t] <= rwords[j][t];
+        if (near && x == x) {
             const u64 k = key_of(x);
             unsigned frac;
             const int b = bin_of(k, sc[j], frac);
