@@ -2,7 +2,7 @@
 """Randomised stress of pem_quantiles_f64_dev against np.percentile (bit for bit): random shapes, percentile sets, pilot strides and
 thresholds (PEM_QUANTILE_PILOT / PEM_QUANTILE_PILOT_MIN are read at every call), distributions with ties, constants, NaN, infinities,
 signed zeros, sorted and periodic columns.  Also drivers.filter_outputs (masks kernel) against its numpy branch.
-    python tools/quantile_stress.py [--cases 400] [--seed 0] [--pilot-only]"""
+    python tools/quantile_stress.py [--cases 400] [--seed 0] [--pilot-only] [--sharded]"""
 import argparse, os, sys
 from pathlib import Path
 import numpy as np, torch
@@ -13,6 +13,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--cases', type=int, default=400)
 ap.add_argument('--seed', type=int, default=0)
 ap.add_argument('--pilot-only', action='store_true', help='every case with a pilot stride and a threshold below its size')
+ap.add_argument('--sharded', action='store_true', help='also the sharded selection (pem_qsel_*) on this one rank, every case')
 args = ap.parse_args()
 lib = _lib.load()
 rng = np.random.default_rng(args.seed)
@@ -55,6 +56,11 @@ for case in range(args.cases):
         bad = np.argwhere(~((got == want) | (np.isnan(got) & np.isnan(want))))
         raise SystemExit(f'case {case}: n={n} m={m} kind={kind} pcts={pcts} pilot={os.environ["PEM_QUANTILE_PILOT"]} min={os.environ["PEM_QUANTILE_PILOT_MIN"]}: '
                          f'{len(bad)} entries differ, first {bad[0]}: got {got[tuple(bad[0])]!r} want {want[tuple(bad[0])]!r}')
+    if args.sharded:
+        from hallthrusterpem_amd.percentiles import column_percentiles_sharded
+        got_s = column_percentiles_sharded(d, pcts)
+        if not np.array_equal(got_s, want, equal_nan=True):
+            raise SystemExit(f'case {case}: n={n} m={m} kind={kind} pcts={pcts}: the sharded selection differs from np.percentile')
     if case % 7 == 0:
         f = float(rng.choice([1.5, 0.0, 3.0]))
         nh, oh = drivers.filter_outputs({'v': a}, iqr_factor=f)
