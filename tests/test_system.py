@@ -134,3 +134,14 @@ def test_the_python_snippet_of_the_readme_runs(tmp_path, monkeypatch):
     exec(compile(code, 'README.md', 'exec'), ns)
     assert 25.0 < float(ns['v'][0]) < 35.0 and len(ns['s']['inputs']) == 12
     assert set(ns['data']) == {'compression', 'nan_idx', 'outlier_idx', 'iqr_factor'} and (tmp_path / 'run' / 'compression' / 'compression.pkl').exists()
+
+
+@pytest.mark.gpu
+def test_the_campaign_example_runs():
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    out = subprocess.run([sys.executable, str(root / 'examples' / 'forward_uq_campaign.py'), '200000'], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert '200000 samples in' in out.stdout and 'T_c' in out.stdout and 'j_ion      median on the axis' in out.stdout
