@@ -65,6 +65,7 @@ SIGNATURES = {
     'pem_qsel_compact_f64_dev': (C.c_int, [_sz, C.c_int, _dp, _sz, _dp, _dp, C.c_int, _dp, _dp, _dp, C.c_int, C.c_int, C.c_uint32, _dp, _dp, _dp]),
     'pem_qsel_select_dev': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_uint32, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     'pem_quantiles_f64_dev': (C.c_int, [_sz, C.c_int, _dp, _sz, C.c_int, _dp, _dp, _dp, _dp, _dp]),
+    'pem_quantiles_strided_f64_dev': (C.c_int, [_sz, C.c_int, _dp, _sz, _sz, C.c_int, _dp, _dp, _dp, _dp, _dp]),
     'pem_quantiles_last_path': (C.c_int, []),
     'pem_row_masks_f64_dev': (C.c_int, [_sz, C.c_int, _dp, _sz, _dp, _dp, _dp, _dp, _dp]),
     'pem_sobol_partial_f64_dev': (C.c_int, [_sz, C.c_int, _sz, _dp, _dp, _dp, _dp, C.c_int, _dp]),

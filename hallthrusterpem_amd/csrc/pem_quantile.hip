@@ -39,7 +39,7 @@ constexpr int LDS_WORDS = 36864;          // 144 KB of 32-bit counters per workg
 constexpr int SORT_CAP = 4096;            // keys a workgroup sorts in LDS (32 KB)
 constexpr int MAX_NC = 4;                 // columns per lane: m <= 256
 constexpr int UNROLL = 8;                 // row groups a wave requests before it consumes any (loads in flight per lane: UNROLL x NC)
-static_assert(PEM_QUANTILE_MAX_Q == 3, "hist2_kernel / compact_kernel are instantiated for 2, 4 and 6 ranks per column");
+static_assert(PEM_QUANTILE_MAX_Q == 6, "hist2_kernel / compact_kernel are instantiated for 2, 4, ... 12 ranks per column");
 
 // order-preserving image of a double (NaN excluded by the callers): negative values reversed, sign bit flipped
 __device__ __forceinline__ u64 key_of(double x) {
@@ -93,7 +93,8 @@ struct Target {          // per (column, wanted rank)
 // m > 64: one row per wave instruction and chunk, column = lane + 64 chunk.
 struct Lanes {
     int rpw, active, col0, rsub;
-    __device__ Lanes(int m, int lane) {
+    size_t cs = 1;       // elements between consecutive columns of a row (1: row-major [n][ld]; n with ld = 1: the transposed [m][n])
+    __device__ Lanes(int m, int lane, size_t col_stride = 1) : cs(col_stride) {
         if (m <= 64) {
             rpw = 64 / m;
             active = lane < rpw * m;
@@ -125,7 +126,7 @@ __device__ __forceinline__ void stream_values(long long n, int m, size_t ld, con
             for (int j = 0; j < NC; ++j) {
                 const int c = L.col0 + 64 * j;
                 ok[u][j] = L.active && c < m && row < n;
-                x[u][j] = ok[u][j] ? data[(size_t)row * ld + c] : 0.0;
+                x[u][j] = ok[u][j] ? data[(size_t)row * ld + (size_t)c * L.cs] : 0.0;
             }
         }
 #pragma unroll
@@ -160,8 +161,8 @@ __global__ void init_columns_kernel(Column* col, Target* tg, int m, int nq, Want
 
 // ---- pass 1: min / max / NaN per column ------------------------------------------------------------------------------
 template <int NC>
-__global__ __launch_bounds__(QBLOCK) void minmax_kernel(long long n, int m, size_t ld, const double* __restrict__ data, Column* __restrict__ col) {
-    const Lanes L(m, threadIdx.x & 63);
+__global__ __launch_bounds__(QBLOCK) void minmax_kernel(long long n, int m, size_t ld, size_t cs, const double* __restrict__ data, Column* __restrict__ col) {
+    const Lanes L(m, threadIdx.x & 63, cs);
     u64 lo[NC], hi[NC];
     int nan[NC];
 #pragma unroll
@@ -224,12 +225,12 @@ __global__ void scale_columns_kernel(Column* col, int m, int bins1) {
 
 // ---- pass 2: histogram per column ------------------------------------------------------------------------------------
 template <int NC>
-__global__ __launch_bounds__(QBLOCK) void hist1_kernel(long long n, int m, size_t ld, const double* __restrict__ data, const Column* __restrict__ col,
+__global__ __launch_bounds__(QBLOCK) void hist1_kernel(long long n, int m, size_t ld, size_t cs, const double* __restrict__ data, const Column* __restrict__ col,
                                                         int bins1, unsigned* __restrict__ hist1) {
     extern __shared__ unsigned lds_hist[];
     for (int i = threadIdx.x; i < m * bins1; i += QBLOCK) lds_hist[i] = 0;
     __syncthreads();
-    const Lanes L(m, threadIdx.x & 63);
+    const Lanes L(m, threadIdx.x & 63, cs);
     Scale sc[NC];
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
@@ -313,13 +314,13 @@ __global__ __launch_bounds__(64) void decide1_kernel(int m, int nt, const Column
 
 // ---- pass 3: histogram of every target's bin -----------------------------------------------------------------------------
 template <int NC, int NT>
-__global__ __launch_bounds__(QBLOCK) void hist2_kernel(long long n, int m, size_t ld, const double* __restrict__ data, const Column* __restrict__ col,
+__global__ __launch_bounds__(QBLOCK) void hist2_kernel(long long n, int m, size_t ld, size_t cs, const double* __restrict__ data, const Column* __restrict__ col,
                                                         const Target* __restrict__ tg, int bins1, int bins2,
                                                         unsigned* __restrict__ hist2) {
     extern __shared__ unsigned lds_hist[];
     for (int i = threadIdx.x; i < m * NT * bins2; i += QBLOCK) lds_hist[i] = 0;
     __syncthreads();
-    const Lanes L(m, threadIdx.x & 63);
+    const Lanes L(m, threadIdx.x & 63, cs);
     Scale sc[NC];
     int tb[NC][NT];
 #pragma unroll
@@ -420,9 +421,9 @@ __global__ __launch_bounds__(64 * MAX_NC) void layout_kernel(int m, int nt, Targ
 
 // ---- pass 4: copy the candidates out ----------------------------------------------------------------------------------------
 template <int NC, int NT>
-__global__ __launch_bounds__(QBLOCK) void compact_kernel(long long n, int m, size_t ld, const double* __restrict__ data, const Column* __restrict__ col,
+__global__ __launch_bounds__(QBLOCK) void compact_kernel(long long n, int m, size_t ld, size_t cs, const double* __restrict__ data, const Column* __restrict__ col,
                                                           Target* __restrict__ tg, int bins1, int bins2, u64* __restrict__ cand) {
-    const Lanes L(m, threadIdx.x & 63);
+    const Lanes L(m, threadIdx.x & 63, cs);
     Scale sc[NC];
     int tb1[NC][NT], tb2[NC][NT];
 #pragma unroll
@@ -679,17 +680,17 @@ __device__ __forceinline__ u64 first_d_of_bin(unsigned mult, int b, u64 D) {
 // Up to 128 columns two workgroups share a CU (16 waves: the pass is as much instruction issue as memory): the bracket histogram
 // gets half the LDS (LDS_WORDS_A) and the registers have to fit twice; four columns per lane need them all.
 constexpr int LDS_WORDS_A = 20224;        // 79 KB of 32-bit counters per workgroup
-template <int NC>
-constexpr int bracket_waves_per_simd() { return NC <= 2 ? 4 : 2; }
 template <int NC, int NQ>
-__global__ __launch_bounds__(QBLOCK) __attribute__((amdgpu_waves_per_eu(bracket_waves_per_simd<NC>()))) void bracket_hist_kernel(long long n, int m, size_t ld, const double* __restrict__ data,
+constexpr int bracket_waves_per_simd() { return (NC <= 2 && NQ <= 3) ? 4 : 2; }
+template <int NC, int NQ>
+__global__ __launch_bounds__(QBLOCK) __attribute__((amdgpu_waves_per_eu(bracket_waves_per_simd<NC, NQ>()))) void bracket_hist_kernel(long long n, int m, size_t ld, size_t cs, const double* __restrict__ data,
                                                                const Bracket* __restrict__ br, int bins, Column* __restrict__ col,
                                                                u64* __restrict__ below, unsigned* __restrict__ hist) {
     extern __shared__ unsigned lds_hist[];                      // [m][NQ][bins] | below [m][NQ]
     unsigned* lds_below = lds_hist + m * NQ * bins;
     for (int i = threadIdx.x; i < m * NQ * (bins + 1); i += QBLOCK) lds_hist[i] = 0;
     __syncthreads();
-    const Lanes L(m, threadIdx.x & 63);
+    const Lanes L(m, threadIdx.x & 63, cs);
     u64 blo[NC][NQ], bspan[NC][NQ];
     unsigned bmult[NC][NQ], nbelow[NC][NQ], bwords[NC][NQ];
     int bshift[NC][NQ], nan[NC];
@@ -796,11 +797,11 @@ __global__ __launch_bounds__(64) void decide_bracket_kernel(int nt, Column* __re
 // pass B: copy out the values of the chosen sub-bins.  (Parking the hits in LDS and appending them after the last row, so that no
 // wave waits for a global atomic in mid-stream, measured the same 1.67 ms as appending on the spot: not kept.)
 template <int NC, int NQ>
-__global__ __launch_bounds__(QBLOCK) void compact_bracket_kernel(long long n, int m, size_t ld, const double* __restrict__ data,
+__global__ __launch_bounds__(QBLOCK) void compact_bracket_kernel(long long n, int m, size_t ld, size_t cs, const double* __restrict__ data,
                                                                   const Bracket* __restrict__ br, Target* __restrict__ tg,
                                                                   u64* __restrict__ cand) {
     constexpr int NT = 2 * NQ;
-    const Lanes L(m, threadIdx.x & 63);
+    const Lanes L(m, threadIdx.x & 63, cs);
     // per (column, quantile): the key range of the sub-bins its list owners collect (two adjacent ranks: one sub-bin, or two
     // neighbours), found from the binning itself; a value is tested against its high words only
     u64 rlo[NC][NQ], rspan[NC][NQ];
@@ -965,12 +966,14 @@ int pow2_at_most(long long x, int cap) {
 static std::atomic<int> g_last_path{0};
 extern "C" int pem_quantiles_last_path(void) { return g_last_path.load(); }
 
-extern "C" int pem_quantiles_f64_dev(size_t n, int m, const double* data, size_t ld, int nq, const uint64_t* rank_prev, const uint64_t* rank_next,
-                                     const double* gamma, double* out, pem_stream_t stream) {
+extern "C" int pem_quantiles_strided_f64_dev(size_t n, int m, const double* data, size_t ld, size_t cs, int nq, const uint64_t* rank_prev,
+                                             const uint64_t* rank_next, const double* gamma, double* out, pem_stream_t stream) {
     if (m < 1 || m > 64 * MAX_NC) return pem::fail(PEM_ERR_INVALID_ARG, "pem_quantiles: 1 <= m <= %d columns", 64 * MAX_NC);
-    if (nq < 1 || nq > PEM_QUANTILE_MAX_Q) return pem::fail(PEM_ERR_INVALID_ARG, "pem_quantiles: 1 <= nq <= %d per call", PEM_QUANTILE_MAX_Q);
+    if (cs < 1 || (cs == 1 ? ld < (size_t)m : (ld != 1 || cs < n)))
+        return pem::fail(PEM_ERR_INVALID_ARG, "pem_quantiles: rows of m columns (column stride 1, ld >= m) or columns of n rows (ld 1, column stride >= n)");
+    if (nq < 1 || nq > (m <= 128 ? PEM_QUANTILE_MAX_Q : PEM_QUANTILE_MAX_Q_WIDE))
+        return pem::fail(PEM_ERR_INVALID_ARG, "pem_quantiles: 1 <= nq <= %d per call (%d for more than 128 columns)", PEM_QUANTILE_MAX_Q, PEM_QUANTILE_MAX_Q_WIDE);
     if (n == 0) return pem::fail(PEM_ERR_INVALID_ARG, "pem_quantiles: no samples");
-    if (ld < (size_t)m) return pem::fail(PEM_ERR_INVALID_ARG, "pem_quantiles: leading dimension smaller than m");
     if (!data || !rank_prev || !rank_next || !gamma || !out) return pem::fail(PEM_ERR_INVALID_ARG, "pem_quantiles: NULL array");
     for (int q = 0; q < nq; ++q)
         if (rank_prev[q] >= n || rank_next[q] >= n || rank_prev[q] > rank_next[q])
@@ -979,7 +982,8 @@ extern "C" int pem_quantiles_f64_dev(size_t n, int m, const double* data, size_t
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int nt = 2 * nq;
     const int bins1 = pow2_at_most(LDS_WORDS / m, 4096), bins2 = pow2_at_most(LDS_WORDS / (m * nt), 4096);
-    int binsA = pow2_at_most((m <= 128 ? LDS_WORDS_A : LDS_WORDS) / (m * nq) - 1, 4096);   // the pilot form's histogram inside a bracket (+ 1 counter)
+    // (four quantiles or more: the brackets' registers leave room for one workgroup per CU anyway -- it gets all of the LDS)
+    int binsA = pow2_at_most(((m <= 128 && nq <= 3) ? LDS_WORDS_A : LDS_WORDS) / (m * nq) - 1, 4096);   // the pilot form's histogram inside a bracket (+ 1 counter)
     if (const char* e = getenv("PEM_QUANTILE_BINSA")) binsA = pow2_at_most(atoll(e) < binsA ? atoll(e) : binsA, 4096);
 
     // the pilot form: every `pilot`-th row brackets the wanted ranks (PEM_QUANTILE_PILOT: the stride, 0 = never;
@@ -1072,36 +1076,61 @@ extern "C" int pem_quantiles_f64_dev(size_t n, int m, const double* data, size_t
         else if (nc == 2) { CALL(2); } \
         else { CALL(4); }          \
     } while (0)
-#define Q_BY_NT(CALL, NC_)             \
+#define Q_BY_NT_SMALL(CALL, NC_)       \
     do {                               \
         if (nt == 2) { CALL(NC_, 2); } \
         else if (nt == 4) { CALL(NC_, 4); } \
         else { CALL(NC_, 6); }         \
     } while (0)
-#define Q_BY_NQ(CALL, NC_)             \
+#define Q_BY_NT_ALL(CALL, NC_)         \
+    do {                               \
+        if (nt == 2) { CALL(NC_, 2); } \
+        else if (nt == 4) { CALL(NC_, 4); } \
+        else if (nt == 6) { CALL(NC_, 6); } \
+        else if (nt == 8) { CALL(NC_, 8); } \
+        else if (nt == 10) { CALL(NC_, 10); } \
+        else { CALL(NC_, 12); }        \
+    } while (0)
+#define Q_BY_NQ_SMALL(CALL, NC_)       \
     do {                               \
         if (nq == 1) { CALL(NC_, 1); } \
         else if (nq == 2) { CALL(NC_, 2); } \
         else { CALL(NC_, 3); }         \
     } while (0)
+#define Q_BY_NQ_ALL(CALL, NC_)         \
+    do {                               \
+        if (nq == 1) { CALL(NC_, 1); } \
+        else if (nq == 2) { CALL(NC_, 2); } \
+        else if (nq == 3) { CALL(NC_, 3); } \
+        else if (nq == 4) { CALL(NC_, 4); } \
+        else if (nq == 5) { CALL(NC_, 5); } \
+        else { CALL(NC_, 6); }         \
+    } while (0)
+// more than three quantiles per call for up to 128 columns only (four columns per lane run out of registers: Q_MAX_WIDE)
+#define Q_BY_NT_1 Q_BY_NT_ALL
+#define Q_BY_NT_2 Q_BY_NT_ALL
+#define Q_BY_NT_4 Q_BY_NT_SMALL
+#define Q_BY_NQ_1 Q_BY_NQ_ALL
+#define Q_BY_NQ_2 Q_BY_NQ_ALL
+#define Q_BY_NQ_4 Q_BY_NQ_SMALL
 
     // the four passes over rows 0, step, 2 step, ... (`rows` of them, leading dimension ldd): x_(rank) of every target ends in tg[].answer
     auto four_passes = [&](size_t rows, size_t ldd, const Wanted& ww) -> int {
         const dim3 grid = grid_for(rows);
         Q_TRY(hipMemsetAsync(hist1, 0, o_tot + 256 - o_h1, st));            // hist1, hist2, total
         hipLaunchKernelGGL(init_columns_kernel, dim3(cblocks), dim3(64), 0, st, col, tg, m, nq, ww);
-#define Q_MINMAX(NC_) hipLaunchKernelGGL(minmax_kernel<NC_>, grid, blk, 0, st, (long long)rows, m, ldd, data, col)
+#define Q_MINMAX(NC_) hipLaunchKernelGGL(minmax_kernel<NC_>, grid, blk, 0, st, (long long)rows, m, ldd, cs, data, col)
         Q_BY_NC(Q_MINMAX);
         hipLaunchKernelGGL(scale_columns_kernel, dim3(cblocks), dim3(64), 0, st, col, m, bins1);
 #define Q_HIST1(NC_)                                                                                       \
     Q_LDS(hist1_kernel<NC_>);                                                                              \
-    hipLaunchKernelGGL(hist1_kernel<NC_>, grid, blk, lds1, st, (long long)rows, m, ldd, data, col, bins1, hist1)
+    hipLaunchKernelGGL(hist1_kernel<NC_>, grid, blk, lds1, st, (long long)rows, m, ldd, cs, data, col, bins1, hist1)
         Q_BY_NC(Q_HIST1);
         hipLaunchKernelGGL(decide1_kernel, dim3((unsigned)(m * nt)), dim3(64), 0, st, m, nt, col, hist1, bins1, tg);
 #define Q_HIST2_(NC_, NT_)                                                                                                  \
     Q_LDS((hist2_kernel<NC_, NT_>));                                                                                        \
-    hipLaunchKernelGGL((hist2_kernel<NC_, NT_>), grid, blk, lds2, st, (long long)rows, m, ldd, data, col, tg, bins1, bins2, hist2)
-#define Q_HIST2(NC_) Q_BY_NT(Q_HIST2_, NC_)
+    hipLaunchKernelGGL((hist2_kernel<NC_, NT_>), grid, blk, lds2, st, (long long)rows, m, ldd, cs, data, col, tg, bins1, bins2, hist2)
+#define Q_HIST2(NC_) Q_BY_NT_##NC_(Q_HIST2_, NC_)
         Q_BY_NC(Q_HIST2);
         hipLaunchKernelGGL(decide2_kernel, dim3((unsigned)(m * nt)), dim3(64), 0, st, nt, hist2, bins2, tg);
         hipLaunchKernelGGL(layout_kernel, dim3(1), dim3(64 * MAX_NC), 0, st, m, nt, tg, total);
@@ -1112,8 +1141,8 @@ extern "C" int pem_quantiles_f64_dev(size_t n, int m, const double* data, size_t
         Q_TRY(grow_candidates(h_total));
         u64* cand = cand_buf;
 #define Q_COMPACT_(NC_, NT_) \
-    hipLaunchKernelGGL((compact_kernel<NC_, NT_>), grid, blk, 0, st, (long long)rows, m, ldd, data, col, tg, bins1, bins2, cand)
-#define Q_COMPACT(NC_) Q_BY_NT(Q_COMPACT_, NC_)
+    hipLaunchKernelGGL((compact_kernel<NC_, NT_>), grid, blk, 0, st, (long long)rows, m, ldd, cs, data, col, tg, bins1, bins2, cand)
+#define Q_COMPACT(NC_) Q_BY_NT_##NC_(Q_COMPACT_, NC_)
         Q_BY_NC(Q_COMPACT);
         hipLaunchKernelGGL(select_kernel, dim3((unsigned)(m * nt)), blk, 0, st, nt, tg, cand, incomplete);
         Q_TRY(hipGetLastError());
@@ -1146,8 +1175,8 @@ extern "C" int pem_quantiles_f64_dev(size_t n, int m, const double* data, size_t
         hipLaunchKernelGGL(init_columns_kernel, dim3(cblocks), dim3(64), 0, st, col, tg, m, nq, w);
 #define Q_BRHIST_(NC_, NQ_)                                                                                                  \
     Q_LDS((bracket_hist_kernel<NC_, NQ_>));                                                                                  \
-    hipLaunchKernelGGL((bracket_hist_kernel<NC_, NQ_>), grid, blk, ldsA, st, (long long)n, m, ld, data, br, binsA, col, below, histA)
-#define Q_BRHIST(NC_) Q_BY_NQ(Q_BRHIST_, NC_)
+    hipLaunchKernelGGL((bracket_hist_kernel<NC_, NQ_>), grid, blk, ldsA, st, (long long)n, m, ld, cs, data, br, binsA, col, below, histA)
+#define Q_BRHIST(NC_) Q_BY_NQ_##NC_(Q_BRHIST_, NC_)
         Q_BY_NC(Q_BRHIST);
         hipLaunchKernelGGL(decide_bracket_kernel, dim3((unsigned)(m * nt)), dim3(64), 0, st, nt, col, br, below, histA, binsA, tg, outside);
         hipLaunchKernelGGL(layout_kernel, dim3(1), dim3(64 * MAX_NC), 0, st, m, nt, tg, total);
@@ -1160,8 +1189,8 @@ extern "C" int pem_quantiles_f64_dev(size_t n, int m, const double* data, size_t
             Q_TRY(grow_candidates(h_tot[0]));
             u64* cand = cand_buf;
 #define Q_BRCOMPACT_(NC_, NQ_) \
-    hipLaunchKernelGGL((compact_bracket_kernel<NC_, NQ_>), grid, blk, 0, st, (long long)n, m, ld, data, br, tg, cand)
-#define Q_BRCOMPACT(NC_) Q_BY_NQ(Q_BRCOMPACT_, NC_)
+    hipLaunchKernelGGL((compact_bracket_kernel<NC_, NQ_>), grid, blk, 0, st, (long long)n, m, ld, cs, data, br, tg, cand)
+#define Q_BRCOMPACT(NC_) Q_BY_NQ_##NC_(Q_BRCOMPACT_, NC_)
             Q_BY_NC(Q_BRCOMPACT);
             hipLaunchKernelGGL(select_kernel, dim3((unsigned)(m * nt)), blk, 0, st, nt, tg, cand, incomplete);
             Q_TRY(hipGetLastError());
@@ -1196,12 +1225,26 @@ extern "C" int pem_quantiles_f64_dev(size_t n, int m, const double* data, size_t
 #undef Q_HIST2_
 #undef Q_HIST1
 #undef Q_MINMAX
-#undef Q_BY_NQ
-#undef Q_BY_NT
+#undef Q_BY_NQ_4
+#undef Q_BY_NQ_2
+#undef Q_BY_NQ_1
+#undef Q_BY_NT_4
+#undef Q_BY_NT_2
+#undef Q_BY_NT_1
+#undef Q_BY_NQ_ALL
+#undef Q_BY_NQ_SMALL
+#undef Q_BY_NT_ALL
+#undef Q_BY_NT_SMALL
 #undef Q_BY_NC
 #undef Q_LDS
 #undef Q_TRY
     return cleanup(PEM_OK);
+}
+
+extern "C" int pem_quantiles_f64_dev(size_t n, int m, const double* data, size_t ld, int nq, const uint64_t* rank_prev, const uint64_t* rank_next,
+                                     const double* gamma, double* out, pem_stream_t stream) {
+    if (ld < (size_t)(m > 0 ? m : 0)) return pem::fail(PEM_ERR_INVALID_ARG, "pem_quantiles: leading dimension smaller than m");
+    return pem_quantiles_strided_f64_dev(n, m, data, ld, 1, nq, rank_prev, rank_next, gamma, out, stream);
 }
 
 // ---- multi-rank building blocks (one level each; hallthrusterpem_amd/percentiles.py) ---------------------------------------
@@ -1231,9 +1274,9 @@ extern "C" int pem_key_minmax_f64_dev(size_t n, int m, const double* data, size_
     if (n) {
         const int nc = m <= 64 ? 1 : (m <= 128 ? 2 : 4);
         const dim3 grid = stream_grid(n, m), blk(QBLOCK);
-        if (nc == 1) hipLaunchKernelGGL(minmax_kernel<1>, grid, blk, 0, st, (long long)n, m, ld, data, col);
-        else if (nc == 2) hipLaunchKernelGGL(minmax_kernel<2>, grid, blk, 0, st, (long long)n, m, ld, data, col);
-        else hipLaunchKernelGGL(minmax_kernel<4>, grid, blk, 0, st, (long long)n, m, ld, data, col);
+        if (nc == 1) hipLaunchKernelGGL(minmax_kernel<1>, grid, blk, 0, st, (long long)n, m, ld, (size_t)1, data, col);
+        else if (nc == 2) hipLaunchKernelGGL(minmax_kernel<2>, grid, blk, 0, st, (long long)n, m, ld, (size_t)1, data, col);
+        else hipLaunchKernelGGL(minmax_kernel<4>, grid, blk, 0, st, (long long)n, m, ld, (size_t)1, data, col);
     }
     hipLaunchKernelGGL(export_minmax_kernel, dim3((m + 63) / 64), dim3(64), 0, st, col, m, (u64*)kmin, (u64*)kmax, (int*)has_nan);
     const hipError_t e = hipGetLastError();
@@ -1677,7 +1720,7 @@ int pem_qsel_decide1_dev(int m, int nt, const uint64_t* kmin, const uint64_t* km
 int pem_qsel_hist2_f64_dev(size_t n, int m, const double* data, size_t ld, const uint64_t* kmin, const uint64_t* kmax, int nt,
                            const int32_t* bin1, int bins1, int bins2, uint32_t* hist2, pem_stream_t stream) {
     if (int rc = qsel_check("pem_qsel_hist2", n, m, ld, data)) return rc;
-    if (nt != 2 && nt != 4 && nt != 6) return pem::fail(PEM_ERR_INVALID_ARG, "pem_qsel_hist2: 2, 4 or 6 targets per column");
+    if (nt < 2 || nt > 2 * PEM_QUANTILE_MAX_Q || (nt & 1)) return pem::fail(PEM_ERR_INVALID_ARG, "pem_qsel_hist2: 2, 4, ... %d targets per column", 2 * PEM_QUANTILE_MAX_Q);
     if (!kmin || !kmax || !bin1 || !hist2) return pem::fail(PEM_ERR_INVALID_ARG, "pem_qsel_hist2: NULL array");
     if (bins1 < 1 || bins2 < 1 || (long long)m * nt * bins2 > LDS_WORDS)
         return pem::fail(PEM_ERR_INVALID_ARG, "pem_qsel_hist2: m * nt * bins2 must not exceed %d", LDS_WORDS);
@@ -1698,11 +1741,22 @@ int pem_qsel_hist2_f64_dev(size_t n, int m, const double* data, size_t ld, const
     do {                                 \
         if (nt == 2) H2(NC_, 2);         \
         else if (nt == 4) H2(NC_, 4);    \
+        else if (nt == 6) H2(NC_, 6);    \
+        else if (nt == 8) H2(NC_, 8);    \
+        else if (nt == 10) H2(NC_, 10);  \
+        else H2(NC_, 12);                \
+    } while (0)
+#define H2_NT_SMALL(NC_)                 \
+    do {                                 \
+        if (nt == 2) H2(NC_, 2);         \
+        else if (nt == 4) H2(NC_, 4);    \
         else H2(NC_, 6);                 \
     } while (0)
+    if (nc == 4 && nt > 2 * PEM_QUANTILE_MAX_Q_WIDE) return pem::fail(PEM_ERR_INVALID_ARG, "pem_qsel_hist2: at most %d targets for more than 128 columns", 2 * PEM_QUANTILE_MAX_Q_WIDE);
     if (nc == 1) H2_NT(1);
     else if (nc == 2) H2_NT(2);
-    else H2_NT(4);
+    else H2_NT_SMALL(4);
+#undef H2_NT_SMALL
 #undef H2_NT
 #undef H2
     HIP_TRY(hipGetLastError());
@@ -1726,7 +1780,7 @@ int pem_qsel_compact_f64_dev(size_t n, int m, const double* data, size_t ld, con
                              const int32_t* bin1, const int32_t* bin2, const int32_t* done, int bins1, int bins2, uint32_t list_len,
                              uint64_t* cand, uint32_t* cursor, pem_stream_t stream) {
     if (int rc = qsel_check("pem_qsel_compact", n, m, ld, data)) return rc;
-    if (nt != 2 && nt != 4 && nt != 6) return pem::fail(PEM_ERR_INVALID_ARG, "pem_qsel_compact: 2, 4 or 6 targets per column");
+    if (nt < 2 || nt > 2 * PEM_QUANTILE_MAX_Q || (nt & 1)) return pem::fail(PEM_ERR_INVALID_ARG, "pem_qsel_compact: 2, 4, ... %d targets per column", 2 * PEM_QUANTILE_MAX_Q);
     if (!kmin || !kmax || !bin1 || !bin2 || !done || !cand || !cursor || list_len < 1) return pem::fail(PEM_ERR_INVALID_ARG, "pem_qsel_compact: bad arguments");
     hipStream_t st = static_cast<hipStream_t>(stream);
     HIP_TRY(hipMemsetAsync(cand, 0xff, sizeof(uint64_t) * (size_t)m * nt * list_len, st));       // padding: ~0, above every key
@@ -1741,11 +1795,22 @@ int pem_qsel_compact_f64_dev(size_t n, int m, const double* data, size_t ld, con
     do {                                 \
         if (nt == 2) CP(NC_, 2);         \
         else if (nt == 4) CP(NC_, 4);    \
+        else if (nt == 6) CP(NC_, 6);    \
+        else if (nt == 8) CP(NC_, 8);    \
+        else if (nt == 10) CP(NC_, 10);  \
+        else CP(NC_, 12);                \
+    } while (0)
+#define CP_NT_SMALL(NC_)                 \
+    do {                                 \
+        if (nt == 2) CP(NC_, 2);         \
+        else if (nt == 4) CP(NC_, 4);    \
         else CP(NC_, 6);                 \
     } while (0)
+    if (nc == 4 && nt > 2 * PEM_QUANTILE_MAX_Q_WIDE) return pem::fail(PEM_ERR_INVALID_ARG, "pem_qsel_compact: at most %d targets for more than 128 columns", 2 * PEM_QUANTILE_MAX_Q_WIDE);
     if (nc == 1) CP_NT(1);
     else if (nc == 2) CP_NT(2);
-    else CP_NT(4);
+    else CP_NT_SMALL(4);
+#undef CP_NT_SMALL
 #undef CP_NT
 #undef CP
     HIP_TRY(hipGetLastError());

@@ -23,6 +23,9 @@ COORDS_STR_ID = '_coords'      # amisc.typing.COORDS_STR_ID as the reference use
 
 
 # ------------------------------------------------------------------------------------------- percentiles over the samples
+MAX_Q, MAX_Q_WIDE = 6, 3     # include/pem_hip.h PEM_QUANTILE_MAX_Q, PEM_QUANTILE_MAX_Q_WIDE: quantiles per selection (<= 128 / <= 256 columns)
+
+
 def column_percentiles(a, percentiles):
     """`np.percentile(a, percentiles, axis=0)` (method 'linear') of a CUDA tensor `a` of shape (n, ...), bit for bit, by exact
     selection on the device (`pem_quantiles_f64_dev`, csrc/pem_quantile.hip) -- the percentiles of gen_data.py:125-174 and
@@ -48,22 +51,28 @@ def column_percentiles(a, percentiles):
     gamma = virtual - prev                                  # (numpy takes the weight from the clipped index as well)
     rank_prev = np.where(prev < 0, n - 1, prev).astype(np.uint64)
     rank_next = np.where(nxt < 0, n - 1, nxt).astype(np.uint64)
-    flat = a.double().reshape(n, -1)
-    if not flat.is_contiguous():
+    a = a.double()
+    # a (n, m) view whose columns are contiguous arrays -- e.g. `batch.qoi.T`, the [3][n] reduced-QoI tensor seen as (n, 3) --
+    # is read in place (`pem_quantiles_strided_f64_dev`): the three scalar QoIs of a campaign in ONE selection, without a copy
+    transposed = a.dim() == 2 and a.shape[1] > 1 and a.stride(0) == 1 and a.stride(1) >= n
+    flat = a if transposed else a.reshape(n, -1)
+    if not transposed and not flat.is_contiguous():
         flat = flat.contiguous()
     m = flat.shape[1]
+    ld, cs = (1, flat.stride(1)) if transposed else (m, 1)
     out = torch.empty((q.size, m), dtype=torch.float64, device=flat.device)
     lib = _lib.load()
     stream = C.c_void_p(torch.cuda.current_stream(flat.device).cuda_stream)
     with torch.cuda.device(flat.device):
-        for c0 in range(0, m, 256):                         # 256 columns and three quantiles per call
+        for c0 in range(0, m, 256):                         # 256 columns and six quantiles (three for more than 128 columns) per call
             mc = min(256, m - c0)
-            for i0 in range(0, q.size, 3):
-                rp, rn, gm = (np.ascontiguousarray(v[i0:i0 + 3]) for v in (rank_prev, rank_next, gamma))
+            step = MAX_Q if mc <= 128 else MAX_Q_WIDE
+            for i0 in range(0, q.size, step):
+                rp, rn, gm = (np.ascontiguousarray(v[i0:i0 + step]) for v in (rank_prev, rank_next, gamma))
                 # the call writes rows of mc values: straight into `out` when that is all of its columns
                 part = out[i0:i0 + rp.size] if mc == m else torch.empty((rp.size, mc), dtype=torch.float64, device=flat.device)
-                _lib.check(lib.pem_quantiles_f64_dev(n, mc, C.c_void_p(flat.data_ptr() + 8 * c0), m, rp.size, C.c_void_p(rp.ctypes.data),
-                                                     C.c_void_p(rn.ctypes.data), C.c_void_p(gm.ctypes.data), C.c_void_p(part.data_ptr()), stream))
+                _lib.check(lib.pem_quantiles_strided_f64_dev(n, mc, C.c_void_p(flat.data_ptr() + 8 * c0 * cs), ld, cs, rp.size, C.c_void_p(rp.ctypes.data),
+                                                             C.c_void_p(rn.ctypes.data), C.c_void_p(gm.ctypes.data), C.c_void_p(part.data_ptr()), stream))
                 if mc != m:
                     out[i0:i0 + rp.size, c0:c0 + mc] = part
     out = out.reshape((q.size,) + tuple(a.shape[1:]))
@@ -95,13 +104,29 @@ def _row_masks(a, lo, hi, per_sample: int):
     return nan.bool(), count
 
 
-def filter_outputs(outputs: dict, iqr_factor: float = 1.5, group=None, sharded: bool | None = None):
+def _check_sharded_call(variables: dict, group=None):
+    """Every rank of a sharded (collective) statistics call must bring the same variables, in the same order, with the same
+    trailing shapes: all-gather a small header and raise on EVERY rank if they differ -- the alternative is a job that hangs in
+    the first all-reduce whose sizes do not match."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) < 2:
+        return
+    header = [(str(k), tuple(int(d) for d in v.shape[1:])) for k, v in variables.items()]
+    seen = [None] * dist.get_world_size(group)
+    dist.all_gather_object(seen, header, group=group)
+    if any(h != seen[0] for h in seen):
+        raise ValueError(f'sharded statistics: the ranks do not bring the same variables / trailing shapes: {seen}')
+
+
+def filter_outputs(outputs: dict, iqr_factor: float = 1.5, group=None, sharded: bool = False):
     """NaN and interquartile-range outlier masks per output variable; mirrors gen_data.py:125-174.
 
-    sharded (default: whenever a process group of more than one rank is initialised): `outputs` is THIS rank's shard of the
-    samples; p25 / p75 are then those of ALL ranks' samples (`percentiles.column_percentiles_sharded`, or its numpy restatement
-    for numpy arrays) and the masks returned are those of the local samples -- together the masks the reference computes on
-    the whole data set.
+    sharded (opt-in; the multi-rank drivers pass True): `outputs` is THIS rank's shard of the samples; p25 / p75 are then those
+    of ALL ranks' samples (`percentiles.column_percentiles_sharded`, or its numpy restatement for numpy arrays) and the masks
+    returned are those of the local samples -- together the masks the reference computes on the whole data set.  The call is
+    then a COLLECTIVE: every rank of `group` must make it, with the same variables in the same order and the same trailing
+    shapes (checked before the first pass: `_check_sharded_call`; a mismatch raises on every rank instead of hanging).
+    The default treats `outputs` as the whole data set, as the reference does, whatever process group exists.
 
     `outputs`: {name: array (num_samples, ...)} of numeric numpy arrays or torch tensors (device tensors stay on
     the device).  Names containing '_coords' and the name 'errors' are skipped.  A sample is an outlier of a
@@ -110,9 +135,8 @@ def filter_outputs(outputs: dict, iqr_factor: float = 1.5, group=None, sharded: 
     Returns (nan_idx, outlier_idx): dicts of boolean arrays of shape (num_samples,)."""
     nan_idx, outlier_idx = {}, {}
     cnt_thresh = 0.75
-    if sharded is None:
-        import torch.distributed as dist
-        sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if sharded:
+        _check_sharded_call({k: v for k, v in outputs.items() if COORDS_STR_ID not in str(k) and str(k) != 'errors'}, group)
     for var, arr in outputs.items():
         if COORDS_STR_ID in str(var) or str(var) == 'errors':
             continue
@@ -217,24 +241,72 @@ def forward_uq(n: int, seed: int = 0, method: str = 'mc', profile: bool = False,
 
 
 def percentile_bands(outputs: dict, percentiles=(5.0, 50.0, 95.0), names=('V_cc', 'div_angle', 'T_c', 'j_ion'), group=None,
-                     sharded: bool | None = None):
+                     sharded: bool = False):
     """The 5 / 50 / 95 % bands monte_carlo.py:363-658 draws from its prior / posterior predictive samples
     (`np.percentile(ys, x, axis=0)`), for the device-resident outputs of `forward_uq`: {name: (len(percentiles), ...) CUDA
     tensor}, equal to numpy's values bit for bit (`column_percentiles`).  Samples flagged `invalid` are kept, as there.
 
-    sharded (default: whenever a process group of more than one rank is initialised): `outputs` is THIS rank's shard of the
-    campaign (`forward_uq(..., rank=, world=)`) and the bands are those of ALL ranks' samples, the same on every rank --
-    `percentiles.column_percentiles_sharded`: min / max and two histograms all-reduced, a few hundred candidates per wanted rank
-    all-gathered, nothing else crosses xGMI."""
+    sharded (opt-in; a collective -- every rank of `group` must call with the same names and shapes, see `filter_outputs`):
+    `outputs` is THIS rank's shard of the campaign (`forward_uq(..., rank=, world=)`) and the bands are those of ALL ranks'
+    samples, the same on every rank -- `percentiles.column_percentiles_sharded`: min / max and two histograms all-reduced, a few
+    hundred candidates per wanted rank all-gathered, nothing else crosses xGMI."""
     import torch
-    if sharded is None:
-        import torch.distributed as dist
-        sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     if not sharded:
         return {k: column_percentiles(outputs[k], list(percentiles)) for k in names if k in outputs}
+    _check_sharded_call({k: outputs[k] for k in names if k in outputs}, group)
     from .percentiles import column_percentiles_sharded
     return {k: torch.from_numpy(np.ascontiguousarray(column_percentiles_sharded(outputs[k], list(percentiles), group=group))).to(outputs[k].device)
             for k in names if k in outputs}
+
+
+def _stacked_rows(tensors):
+    """1-D CUDA tensors that are equally spaced rows of ONE allocation -- `forward_uq`'s V_cc, div_angle, T_c are rows of the
+    batch's [3][n] reduced-QoI tensor -- as an (n, k) strided view (no copy), or None."""
+    import torch
+    t0 = tensors[0]
+    if len(tensors) < 2 or any(t.dim() != 1 or not t.is_cuda or t.dtype != torch.float64 or t.numel() != t0.numel() or t.stride(0) != 1
+                               or t.untyped_storage().data_ptr() != t0.untyped_storage().data_ptr() for t in tensors):
+        return None
+    n, step = t0.numel(), tensors[1].storage_offset() - t0.storage_offset()
+    if step < n or any(t.storage_offset() != t0.storage_offset() + i * step for i, t in enumerate(tensors)):
+        return None
+    return torch.as_strided(t0, (n, len(tensors)), (1, step))
+
+
+def campaign_statistics(outputs: dict, iqr_factor: float = 1.5, percentiles=(5.0, 50.0, 95.0), names=None):
+    """`filter_outputs` and `percentile_bands` of one campaign's device-resident outputs from ONE selection per variable
+    (gen_data.py:125-174 and monte_carlo.py:363-658 want p25 / p75 and 5 / 50 / 95 % of the same arrays): the five quantiles
+    share the pilot, the counting pass and the copy pass (`pem_quantiles_f64_dev`, up to six per call), and scalar outputs that
+    are rows of one tensor go through one call together.  Returns (nan_idx, outlier_idx, bands), each equal to what the two
+    separate calls return (numpy's values bit for bit)."""
+    import torch
+    names = [k for k in (outputs if names is None else names) if k in outputs and COORDS_STR_ID not in str(k) and str(k) != 'errors']
+    pct = [25.0, 75.0] + [float(x) for x in percentiles]
+    q = {}
+    scalars = [k for k in names if outputs[k].dim() == 1]
+    stacked = _stacked_rows([outputs[k] for k in scalars]) if len(scalars) > 1 else None
+    if stacked is not None:
+        qs = column_percentiles(stacked, pct)                               # (len(pct), k)
+        q.update({k: qs[:, i] for i, k in enumerate(scalars)})
+    for k in names:
+        if k not in q:
+            q[k] = column_percentiles(outputs[k], pct)
+    nan_idx, outlier_idx, bands = {}, {}, {}
+    for k in names:
+        a, qk = outputs[k].double(), q[k]
+        per_sample = int(np.prod(a.shape[1:])) if a.dim() > 1 else 1
+        iqr = qk[1] - qk[0]
+        lo, hi = qk[0] - iqr_factor * iqr, qk[1] + iqr_factor * iqr
+        if a.shape[0] > 0 and per_sample <= ROW_MASKS_MAX_M:
+            nan_idx[k], count = _row_masks(a, lo, hi, per_sample)
+        else:
+            rest = tuple(range(1, a.dim()))
+            nan_idx[k] = torch.isnan(a).any(dim=rest) if rest else torch.isnan(a)
+            outside = (a < lo) | (a > hi)
+            count = outside.sum(dim=rest) if rest else outside.long()
+        outlier_idx[k] = count > int(0.75 * per_sample)
+        bands[k] = qk[2:]
+    return nan_idx, outlier_idx, bands
 
 
 def generate_data(system, description: str, num_samples: int = 500, executor=None, verbose: bool = False,

@@ -191,7 +191,7 @@ class NumpyColumns:
                 cand[c, t, :min(mine.size, list_len)] = mine[:list_len]
         return cand, cursor
 
-    # the two ways through a pass of up to three quantiles (`sharded_percentiles` calls these)
+    # the two ways through a pass of up to six quantiles (`sharded_percentiles` calls these)
     def select_pass(self, ranks, kmin, kmax, group):
         return _numpy_pass(self, ranks, kmin, kmax, group)
 
@@ -250,7 +250,7 @@ def select_lists(gathered, bin1, bin2, done, resid, answer):
 
 
 def _numpy_pass(cols: NumpyColumns, ranks, kmin, kmax, group):
-    """One pass (up to three quantiles = six targets per column) of the selection on the numpy restatement, collectives over
+    """One pass (up to six quantiles = twelve targets per column) of the selection on the numpy restatement, collectives over
     gloo.  Returns the (m, nt) keys, or None when the lists would not fit (`_lists_fit`: the level loop takes over)."""
     import torch
     import torch.distributed as dist
@@ -377,12 +377,15 @@ def sharded_percentiles(cols, percentiles, group=None, method: str = 'select'):
     kmin, kmax, nan = cols.reduced_minmax(group) if hasattr(cols, 'reduced_minmax') else _reduce_keys(*cols.minmax(), group)
     empty = kmin > kmax
     out = np.empty((nq, m))
-    for q0 in range(0, nq, 3):                                                    # three quantiles = six ranks per column and pass
-        sel = slice(q0, min(q0 + 3, nq))
+    # six quantiles = twelve ranks per column and pass (three for more than 128 columns: PEM_QUANTILE_MAX_Q / _WIDE): a campaign's
+    # p25 / p75 (the IQR masks) and its 5 / 50 / 95 % bands share the four passes
+    step = 6 if m <= 128 else 3
+    for q0 in range(0, nq, step):
+        sel = slice(q0, min(q0 + step, nq))
         ranks = np.stack([rank_prev[sel], rank_next[sel]], axis=1).reshape(-1)    # [prev0, next0, prev1, ...]
         keys = cols.select_pass(ranks, kmin, kmax, group) if method == 'select' else None
-        if keys is None:
-            keys = cols.levels_pass(ranks, kmin, kmax, group)
+        if keys is None:                                                          # (the level loop takes six ranks at a time)
+            keys = np.concatenate([cols.levels_pass(ranks[r0:r0 + 6], kmin, kmax, group) for r0 in range(0, ranks.size, 6)], axis=1)
         vals = value_of(keys)                                                     # [m][nt]: x_(prev), x_(next) per quantile
         for i, qi in enumerate(range(sel.start, sel.stop)):
             out[qi] = lerp(vals[:, 2 * i], vals[:, 2 * i + 1], gamma[qi])
@@ -470,7 +473,7 @@ class DeviceColumns:
         return kmin.cpu().numpy().view(U64), kmax.cpu().numpy().view(U64), nan.cpu().numpy().astype(np.int64)
 
     def select_pass(self, ranks, kmin, kmax, group):
-        """One pass of the selection (<= 3 quantiles) on the device, the columns MAX_COLUMNS at a time.  (m, nt) keys, or None
+        """One pass of the selection (<= 6 quantiles; <= 3 for more than 128 columns) on the device, the columns MAX_COLUMNS at a time.  (m, nt) keys, or None
         when the candidate lists would not fit (`_lists_fit`)."""
         import torch.distributed as dist
         torch, lib = self.torch, self.lib.load()

@@ -289,14 +289,20 @@ int pem_sparse_grid_values_f64_dev(size_t n, int n_dim, int n_beta, const int32_
  * fully coalesced); for quantile i the caller gives the two ranks
  * numpy's method 'linear' reads (rank_prev[i] <= rank_next[i] < n) and its weight gamma[i] (HOST arrays);
  * out[i][c] = _lerp(x_(rank_prev[i]), x_(rank_next[i]), gamma[i]) of column c, NaN if the column holds a NaN -- equal to
- * np.percentile bit for bit.  nq <= PEM_QUANTILE_MAX_Q per call.  Allocates its workspace and synchronises the stream.
+ * np.percentile bit for bit.  nq <= PEM_QUANTILE_MAX_Q per call (PEM_QUANTILE_MAX_Q_WIDE for m > 128).  Allocates its workspace and synchronises the stream.
  * From n * m = 2^25 values on, every 32nd row is examined first and brackets the wanted ranks, which leaves two passes over the
  * data instead of four; a call whose data defeat the brackets (the counts say so) repeats with the four passes -- the result is
  * the same either way.  Environment: PEM_QUANTILE_PILOT = that stride (0: never), PEM_QUANTILE_PILOT_MIN = the smallest n * m it
  * is used for.  pem_quantiles_last_path(): how the last call went (0 four passes, 1 brackets held, 2 brackets failed, four passes).   */
-#define PEM_QUANTILE_MAX_Q 3
+#define PEM_QUANTILE_MAX_Q 6
+#define PEM_QUANTILE_MAX_Q_WIDE 3      /* per call for 128 < m <= 256 columns */
 int pem_quantiles_f64_dev(size_t n, int m, const double* data, size_t ld, int nq, const uint64_t* rank_prev, const uint64_t* rank_next,
                           const double* gamma, double* out, pem_stream_t stream);
+/* The same over a strided view: value (row, c) at data[row * ld + c * cs] -- (ld >= m, cs = 1) is the form above; (ld = 1, cs >= n)
+ * takes the m columns from m contiguous arrays of n values cs apart, e.g. the [3][n] reduced-QoI tensor of a batch
+ * (V_cc, div_angle, T_c in ONE call instead of three).                                                                            */
+int pem_quantiles_strided_f64_dev(size_t n, int m, const double* data, size_t ld, size_t cs, int nq, const uint64_t* rank_prev,
+                                  const uint64_t* rank_next, const double* gamma, double* out, pem_stream_t stream);
 int pem_quantiles_last_path(void);
 
 /* The per-sample masks of `_filter_outputs` (scripts/gen_data.py:150-168) for one output variable in one pass over it
@@ -330,7 +336,7 @@ int pem_range_narrow_dev(int n_ranges, int bins, const uint32_t* hist, uint64_t*
  * rows; hallthrusterpem_amd/percentiles.py all-reduces kmin / kmax / has_nan (MIN / MAX), hist1 and hist2 (SUM) between them and
  * all-gathers the padded candidate lists, so that every rank takes the same decisions: four streaming passes instead of the
  * eleven levels of pem_range_hist.  All arrays on the device, caller-owned; nt = 2 nq targets per column (the two order
- * statistics of each of nq <= 3 quantiles); nothing here synchronises the stream.
+ * statistics of each of nq <= PEM_QUANTILE_MAX_Q quantiles); nothing here synchronises the stream.
  *   pem_qsel_bins      bins1 / bins2 the histograms use for m columns and nt targets (pure arithmetic: LDS-bound powers of two)
  *   pem_qsel_minmax    kmin / kmax [m]: smallest / largest key of each column (kmin > kmax: no value), has_nan [m]
  *   pem_qsel_hist1     hist1[m][bins1] over [kmin, kmax] (the all-reduced ones): bin = floor(d mult / 2^32), d = (k - kmin) >> shift,

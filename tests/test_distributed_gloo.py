@@ -216,14 +216,21 @@ def _filter_worker(rank, world, port, out_dir):
         out['T_c'][::500] = 5.0
         out['j_ion'][5::2000] *= 1e4
         out['j_ion'][7, 3] = np.nan
-        nan_all, outl_all = filter_outputs(out, sharded=False)                  # the reference's masks of the whole data set
+        nan_all, outl_all = filter_outputs(out)                                 # the reference's masks of the whole data set (the default, process group or not)
         edges = [0, 12_000, n] if world == 2 else [0, 0, 9_000, n]
         lo, hi = edges[rank], edges[rank + 1]
         for mine in ({k: v[lo:hi] for k, v in out.items()}, {k: torch.from_numpy(v[lo:hi]) for k, v in out.items()}):
-            nan_r, outl_r = filter_outputs(mine)                                   # sharded: a process group of `world` ranks is up
+            nan_r, outl_r = filter_outputs(mine, sharded=True)                     # (opt-in: the default treats a rank's data as a whole data set)
             for k in nan_all:
                 assert np.array_equal(np.asarray(nan_r[k]), nan_all[k][lo:hi]) and np.array_equal(np.asarray(outl_r[k]), outl_all[k][lo:hi]), (rank, k)
         assert outl_all['T_c'].sum() >= n // 500 and outl_all['j_ion'].sum() >= 5
+        # a sharded call is a collective: ranks that bring different variables are told so (on every rank) instead of hanging
+        odd = {'T_c': out['T_c'][lo:hi]} if rank == 0 else {'T_c': out['T_c'][lo:hi], 'j_ion': out['j_ion'][lo:hi]}
+        try:
+            filter_outputs(odd, sharded=True)
+            raise AssertionError('mismatched sharded call was accepted')
+        except ValueError as exc:
+            assert 'do not bring the same variables' in str(exc)
         Path(out_dir, f'ok{rank}').write_text('ok')
     finally:
         dist.destroy_process_group()

@@ -219,6 +219,87 @@ def test_row_masks_entry_point_counts_and_errors():
     assert lib.pem_row_masks_f64_dev(0, 4, None, 4, None, None, None, None, None) == 0               # nothing to do
 
 
+def test_five_and_six_quantiles_share_one_selection(pilot_from):
+    """Round 4: up to six quantiles per selection (PEM_QUANTILE_MAX_Q) -- a campaign's p25 / p75 and its 5 / 50 / 95 % bands go
+    through ONE pilot, one counting pass and one copy pass -- in the four-pass form and in the pilot form, ties and NaN included,
+    and three for more than 128 columns (PEM_QUANTILE_MAX_Q_WIDE; the driver splits)."""
+    import ctypes as C
+    import torch
+    from hallthrusterpem_amd import _lib
+    rng = np.random.default_rng(41)
+    five, six = [25.0, 75.0, 5.0, 50.0, 95.0], [0.0, 5.0, 25.0, 50.0, 99.9, 100.0]
+    for shape in ((40_000, 91), (9_000, 3), (5_000, 128), (3_000, 130), (2_000, 256), (6_000, 7, 13)):
+        a = rng.lognormal(0.0, 2.0, shape)
+        a[rng.random(shape[0]) < 0.3] = 1e-20                # 30 % of the rows tied at the minimum: the 5 % and 25 % brackets coincide
+        _check(a, five)
+        _check(a, six)
+    pilot_from(256)                                          # the pilot form from 2^8 values on
+    for shape in ((300_000, 91), (200_000, 3), (100_000, 128)):
+        a = rng.lognormal(0.0, 2.0, shape) * np.where(rng.random(shape) < 0.2, -1.0, 1.0)
+        a[rng.random(shape[0]) < 0.1] = 1e-20
+        _check(a, five)
+        assert _last_path() == 1
+        _check(a, six)
+        assert _last_path() == 1
+    a[777, 1] = np.nan
+    _check(a, five)
+    # the C entry point refuses more than it is instantiated for
+    lib = _lib.load()
+    d = torch.zeros((100, 200), dtype=torch.float64, device='cuda')
+    out = torch.zeros((6, 200), dtype=torch.float64, device='cuda')
+    r = (C.c_uint64 * 6)(*[10] * 6)
+    g = (C.c_double * 6)(*[0.0] * 6)
+    assert lib.pem_quantiles_f64_dev(100, 200, C.c_void_p(d.data_ptr()), 200, 4, r, r, g, C.c_void_p(out.data_ptr()), None) == 1
+    assert lib.pem_quantiles_f64_dev(100, 128, C.c_void_p(d.data_ptr()), 200, 7, r, r, g, C.c_void_p(out.data_ptr()), None) == 1
+    assert lib.pem_quantiles_f64_dev(100, 128, C.c_void_p(d.data_ptr()), 200, 6, r, r, g, C.c_void_p(out.data_ptr()), None) == 0
+
+
+def test_columns_read_in_place_from_a_transposed_tensor(pilot_from):
+    """`pem_quantiles_strided_f64_dev`: the [3][n] reduced-QoI tensor of a batch seen as (n, 3) -- V_cc, div_angle, T_c in ONE
+    selection, without a copy -- equals numpy on the transposed copy; four-pass and pilot form, 1 to 70 columns."""
+    import torch
+    from hallthrusterpem_amd.drivers import column_percentiles
+    rng = np.random.default_rng(43)
+    for pilot in (False, True):
+        if pilot:
+            pilot_from(256)
+        for k, n in ((3, 250_001), (1, 5_000), (2, 70_000), (64, 9_000), (70, 8_000)):
+            rows = rng.lognormal(0.0, 1.5, (k, n + 5))      # rows longer than n: a column stride larger than the row count
+            t = torch.from_numpy(rows).cuda()
+            view = t[:, :n].T                                # (n, k), strides (1, n + 5)
+            assert k == 1 or (view.stride(0) == 1 and not view.is_contiguous())
+            for pcts in ([25.0, 75.0, 5.0, 50.0, 95.0], 50.0):
+                got = column_percentiles(view, pcts).cpu().numpy()
+                assert np.array_equal(got, np.percentile(rows[:, :n].T, pcts, axis=0)), (k, n, pilot)
+
+
+def test_campaign_statistics_equal_the_two_separate_calls():
+    """drivers.campaign_statistics: masks and bands of a campaign from one selection of five quantiles per variable, the three
+    scalar QoIs stacked in one call -- the same masks and the same bands as filter_outputs + percentile_bands, bit for bit."""
+    import torch
+    from hallthrusterpem_amd import drivers
+    out = drivers.forward_uq(400_000, seed=14, keep_profile=True)
+    out['T_c'][::997] = 9.0                                  # outliers of a scalar
+    out['j_ion'][5::4001] *= 1e3                             # whole profiles far outside
+    keep = {k: out[k] for k in ('V_cc', 'div_angle', 'T_c', 'j_ion')}
+    assert drivers._stacked_rows([out[k] for k in ('V_cc', 'div_angle', 'T_c')]) is not None
+    nan_a, outl_a = drivers.filter_outputs(keep)
+    bands_a = drivers.percentile_bands(out)
+    nan_b, outl_b, bands_b = drivers.campaign_statistics(keep)
+    assert set(nan_b) == set(nan_a) == set(keep) and set(bands_b) == set(bands_a)
+    for k in keep:
+        assert torch.equal(nan_a[k], nan_b[k]) and torch.equal(outl_a[k], outl_b[k]), k
+        assert torch.equal(bands_a[k], bands_b[k]), k
+        assert np.array_equal(bands_b[k].cpu().numpy(), np.percentile(out[k].cpu().numpy(), [5.0, 50.0, 95.0], axis=0))
+    assert int(outl_b['T_c'].sum()) >= 400_000 // 997 and int(outl_b['j_ion'].sum()) >= 90
+    # tensors that are not rows of one allocation go one by one, with the same result
+    sep = {k: v.clone() for k, v in keep.items()}
+    assert drivers._stacked_rows([sep[k] for k in ('V_cc', 'div_angle', 'T_c')]) is None
+    nan_c, outl_c, bands_c = drivers.campaign_statistics(sep, names=('T_c', 'j_ion', 'V_cc'))
+    for k in ('T_c', 'j_ion', 'V_cc'):
+        assert torch.equal(nan_c[k], nan_a[k]) and torch.equal(outl_c[k], outl_a[k]) and torch.equal(bands_c[k], bands_a[k])
+
+
 def test_percentile_bands_of_a_forward_uq_campaign():
     from hallthrusterpem_amd import drivers
     out = drivers.forward_uq(300_000, seed=4, keep_profile=True)
@@ -377,8 +458,8 @@ def _two_rank_worker(rank, world, port, out_dir):
         for k, pcts in (('j_ion', [5.0, 50.0, 95.0]), ('T_c', [25.0, 75.0])):
             got = column_percentiles_sharded(mine[k], pcts)
             assert np.array_equal(got, np.percentile(out[k].cpu().numpy(), pcts, axis=0), equal_nan=True), (rank, k)
-        # the driver-level form: the bands of the whole campaign from this rank's shard (sharded by default under a process group)
-        bands = drivers.percentile_bands(mine, names=('T_c', 'j_ion'))
+        # the driver-level form: the bands of the whole campaign from this rank's shard (sharding is opt-in: ADVICE r3)
+        bands = drivers.percentile_bands(mine, names=('T_c', 'j_ion'), sharded=True)
         for k in ('T_c', 'j_ion'):
             assert bands[k].is_cuda and np.array_equal(bands[k].cpu().numpy(), np.percentile(out[k].cpu().numpy(), [5.0, 50.0, 95.0], axis=0), equal_nan=True)
         # ... and the NaN / IQR masks of the whole campaign's data set, for this rank's samples
@@ -386,7 +467,7 @@ def _two_rank_worker(rank, world, port, out_dir):
         whole['T_c'][::777] = 9.0
         whole['j_ion'][123_456, 5] = float('nan')
         nan_all, outl_all = drivers.filter_outputs(whole, sharded=False)
-        nan_r, outl_r = drivers.filter_outputs({k: v[lo:hi].contiguous() for k, v in whole.items()})
+        nan_r, outl_r = drivers.filter_outputs({k: v[lo:hi].contiguous() for k, v in whole.items()}, sharded=True)
         for k in nan_all:
             assert torch.equal(nan_r[k], nan_all[k][lo:hi]) and torch.equal(outl_r[k], outl_all[k][lo:hi]), (rank, k)
         assert int(outl_all['T_c'].sum()) >= n // 777 and int(nan_all['j_ion'].sum()) == 1

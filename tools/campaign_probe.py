@@ -31,8 +31,14 @@ t_model = wall(lambda: drivers.forward_uq(n, seed=2, keep_profile=True))
 t_filter = wall(lambda: drivers.filter_outputs(keep))
 t_bands = wall(lambda: drivers.percentile_bands(out))
 total = t_model + t_filter + t_bands
+t_stats = wall(lambda: drivers.campaign_statistics(keep))
+t_qj = wall(lambda: drivers.column_percentiles(out['j_ion'], [25.0, 75.0, 5.0, 50.0, 95.0]))
+t_qs = wall(lambda: drivers.column_percentiles(drivers._stacked_rows([out[k] for k in ('V_cc', 'div_angle', 'T_c')]), [25.0, 75.0, 5.0, 50.0, 95.0]))
 print(f'forward-UQ campaign, {n} coupled samples, one MI355X (fp64, 91-point profile kept):')
 print(f'  sample + evaluate (forward_uq)          {t_model * 1e3:8.2f} ms   {n / t_model / 1e9:6.2f} G evals/s')
 print(f'  NaN / IQR masks (filter_outputs)        {t_filter * 1e3:8.2f} ms')
 print(f'  5 / 50 / 95 % bands (percentile_bands)  {t_bands * 1e3:8.2f} ms')
 print(f'  whole campaign                          {total * 1e3:8.2f} ms   {n / total / 1e9:6.2f} G evals/s')
+print(f'  masks + bands from ONE selection of five quantiles per variable (campaign_statistics) {t_stats * 1e3:8.2f} ms'
+      f'   [five quantiles of j_ion {t_qj * 1e3:.2f} ms, of the three scalars in one call {t_qs * 1e3:.2f} ms]')
+print(f'  whole campaign, that way                {(t_model + t_stats) * 1e3:8.2f} ms   {n / (t_model + t_stats) / 1e9:6.2f} G evals/s')
