@@ -51,6 +51,7 @@
 #include "pem_math.h"
 #include "pem_hip.h"
 #include "pem_philox.h"
+#include "pem_qfused.h"
 
 #include "pem_model.h"
 
@@ -81,6 +82,8 @@ struct PlumeIO {
     // point but one); 15 * 64 = the tile-interleaved layout of pem_coupled_tiled_f64_dev, whose 15 "arrays" are the rows of
     // one [tiles][15][64] block (R = 1 fast path only: the other plume kernels index the arrays directly).
     long long in_tile_stride = 64;
+    // counting modes (JMODE 4 / 5): brackets in, counts and records out (csrc/pem_qfused.h)
+    pem::CountIO q;
 };
 
 struct CoupledIO {
@@ -205,6 +208,8 @@ __device__ __forceinline__ SampleIn<true> generate_sample(const McDesign& mc, co
 //               densities there (csrc/pem_likelihood.hip's formula); nothing but scalars leaves the chip
 //            (the fused compression mode -- latent = norm(j_ion) @ basis -- is a kernel of its own, one lane per sample:
 //            csrc/pem_latent.hip)
+//            4: as 1, and the staged profile is COUNTED against the brackets of a percentile selection on its way out (count_round);
+//            5: the same without the stores -- the percentiles of a profile that is never written
 // LDS map (doubles): shared by the workgroup: simpson[96][2] | dpoly[32*12];  per wave: params[NROWS][64] |
 // tile[S*91] | 2 (sink).  The Simpson table is padded with zero weights to L*CH <= 96 entries so the angle loop
 // needs no branch.  The den/num partial sums of a round reuse the rows of `params` that the round has consumed.
@@ -219,7 +224,7 @@ constexpr int QPOLY_DOUBLES = (PEM_NDI + PEM_NQB) * PEM_NDC * 2;
 template <int L, int JMODE>
 constexpr int wave_lds_doubles() {
     return param_rows<L>() * WAVE +
-           ((JMODE == 1 || JMODE == 3) ? (WAVE / L) * NANG + 2 : JMODE == 2 ? ((WAVE / L) * NANG + 4) / 2 : 0);
+           ((JMODE == 1 || JMODE == 3 || JMODE == 4 || JMODE == 5) ? (WAVE / L) * NANG + 2 : JMODE == 2 ? ((WAVE / L) * NANG + 4) / 2 : 0);
 }
 template <int L, int JMODE>
 constexpr int fast_lds_doubles() { return TABLE_DOUBLES + WPB * wave_lds_doubles<L, JMODE>(); }
@@ -260,6 +265,7 @@ struct WaveLds {
     const double2* qpoly;    // reduced-QoI mode: [(32+64)*12] {Qd, Qn} coefficients of the Simpson functionals, or nullptr
     double* params;          // [9][64]
     double* tile;            // [S*91] + 2
+    unsigned tile_off;       // its byte offset in the workgroup's dynamic LDS (counting modes)
 };
 
 // The slow, literal evaluation of one lane's chunk of angles: direct exp() of -(alpha_k / alpha)^2 per beam, every
@@ -292,13 +298,104 @@ __device__ __attribute__((noinline)) ChunkSums exact_chunk(double X1a, double X2
     return r;
 }
 
+// ---- counting modes (JMODE 4 / 5): the round tile against the brackets of a percentile selection -------------------------------
+// The profile's percentiles over the samples (gen_data.py:163-168, monte_carlo.py:363-658) need, per (angle, quantile), the
+// number of values below a bracket and the values inside it (csrc/pem_quantile.hip: the pilot form).  A round's S x 91 values sit
+// in LDS in final order, so the wave changes roles once more: lane = angle (two slots: angles 0..63 and 64..90), down the S
+// samples of the round.  Per (value, bracket) one subtraction of high words -- its borrow is "below", t <= words is "inside"
+// (brackets end on whole words and do not overlap: the selection falls back otherwise) -- with the counts in registers for a round
+// and in per-workgroup LDS counters between rounds.  The few per cent of values inside a bracket are noted as one bit per (slot,
+// sample) and leave as 16-byte records {key, angle * nq + quantile}, appended to the wave's own region of the record buffer
+// (no atomics: the count lives in a scalar register) by however many lanes have one left, until none has.
+// Out of line, with its LDS operands as byte offsets into the workgroup's dynamic LDS: inlined into the rounds it cost the kernel
+// 140 registers (one wave per SIMD), and generic pointers would turn its LDS traffic into flat accesses.
+struct QCount {
+    unsigned tab_off;            // LDS [91][NQ] {loh, words}
+    unsigned below_off;          // LDS [NQ][91]
+    pem::Record* rec;            // this wave's region
+    unsigned cap, cnt;           // its size; records produced so far (wave-uniform)
+};
+struct NoCount {};
+
+template <int NQ, int S, bool FULL>
+__device__ __attribute__((noinline)) unsigned count_round(unsigned tab_off, unsigned below_off, unsigned tile_off, pem::Record* rec,
+                                                          unsigned cap, unsigned cnt, int lane, int rows) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const uint2* tab = reinterpret_cast<const uint2*>(smem_raw + tab_off);
+    unsigned* below = reinterpret_cast<unsigned*>(smem_raw + below_off);
+    const double* tile = reinterpret_cast<const double*>(smem_raw + tile_off);
+    unsigned bits = 0;           // bit 16 slot + s: value s of the slot's angle lies inside a bracket
+    static_assert(S <= 16, "one bit per sample and slot");
+#pragma unroll
+    for (int slot = 0; slot < 2; ++slot) {
+        const int col = lane + 64 * slot;
+        const bool on = col < NANG;
+        const int cc = on ? col : NANG - 1;           // idle lanes of the second slot repeat the last angle and keep nothing
+        uint2 tb[NQ];
+        unsigned nb[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            tb[q] = tab[cc * NQ + q];
+            nb[q] = 0;
+        }
+        const int* hw = reinterpret_cast<const int*>(tile) + 2 * cc + 1;   // the high words of this angle's values
+        // (a rolled loop on purpose: fully unrolled, the scheduler hoisted every read of the round and the function took 248 registers)
+        // (comparisons kept as wave masks -- v_cmp into a scalar pair, s_or, and back as a lane condition: written with plain
+        // bools the compiler materialised every one of them as 0 / 1 in a register, 37 instructions per value instead of 19)
+        unsigned mine = 0;
+        const int nrows = FULL ? S : rows;            // (a compile-time trip count lets the loop be unrolled around the wave-level builtins)
+#pragma unroll 4
+        for (int s = 0; s < nrows; ++s) {
+            const unsigned kh = pem::order_key_high(hw[s * 2 * NANG]);
+            unsigned long long in = 0;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                unsigned t;
+                nb[q] += __builtin_sub_overflow(kh, tb[q].x, &t) ? 1u : 0u;
+                in |= __builtin_amdgcn_uicmp(t, tb[q].y, 37 /* ICMP_ULE */);   // (a borrow leaves t above every `words`)
+            }
+            mine |= __builtin_amdgcn_inverse_ballot_w64(in) ? (1u << s) : 0u;
+        }
+        bits |= on ? mine << (16 * slot) : 0u;
+        if (on) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                if (nb[q]) atomicAdd(&below[q * NANG + col], nb[q]);
+        }
+    }
+    while (__ballot(bits != 0)) {
+        const bool has = bits != 0;
+        const int b = has ? __builtin_ctz(bits) : 0;
+        bits &= bits - 1;                              // (0 stays 0)
+        const int col = has ? lane + 64 * (b >> 4) : 0;
+        const double x = tile[(b & 15) * NANG + col];
+        const unsigned kh = pem::order_key_high(__double2hiint(x));
+        int cq = 0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const uint2 e = tab[col * NQ + q];
+            cq = (kh - e.x <= e.y) ? q : cq;
+        }
+        const unsigned long long emit = __ballot(has);
+        const unsigned at = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(emit >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)emit, 0u));
+        if (has && at < cap) {
+            f64x2 r;
+            r.x = __longlong_as_double((long long)pem::order_key(x));
+            r.y = __longlong_as_double((long long)(col * NQ + cq));
+            *reinterpret_cast<f64x2*>(rec + at) = r;
+        }
+        cnt += (unsigned)__popcll(emit);
+    }
+    return cnt;
+}
+
 // One 64-sample tile.  FULL = every sample of the tile exists (the steady state of the persistent loop:
 // no bounds checks and a fixed number of stores, so the compiler can count them); FULL = false is the
 // ragged last tile of a batch.
-template <int L, bool COUPLED, int JMODE, bool FULL>
+template <int L, bool COUPLED, int JMODE, bool FULL, int NQ = 0, class QC = NoCount>
 __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO& cio, const WaveLds& m,
                                              const SampleIn<COUPLED>& in, long long t, int lane, double rad,
-                                             double inv_r2, double inv_2pi_r2) {
+                                             double inv_r2, double inv_2pi_r2, QC& qc) {
     constexpr int S = WAVE / L;             // samples per round
     constexpr int CH = (NANG + L - 1) / L;  // angles per lane
     constexpr int TILE = S * NANG;          // profile values per round tile
@@ -375,7 +472,10 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
         wave_lds_sync();
 
         // ------------------------------ ROUNDS: L lanes per sample ------------------------------
-#pragma unroll
+        // (the counting modes keep the rounds rolled: unrolled four times with count_round inside, the kernel took 340 registers
+        // and one wave per SIMD)
+        constexpr int ROUND_UNROLL = NQ > 0 ? 1 : L;
+#pragma unroll ROUND_UNROLL
         for (int round = 0; round < L; ++round) {
             const int smp = round * S + s;
             double X1 = params[0 * WAVE + smp], X2 = params[1 * WAVE + smp];
@@ -495,6 +595,13 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
                     wave_lds_sync();
                     continue;
                 }
+                if constexpr (JMODE == 5) {             // counted, never stored
+                    const long long left = io.n - first;
+                    qc.cnt = count_round<NQ, S, FULL>(qc.tab_off, qc.below_off, m.tile_off, qc.rec, qc.cap, qc.cnt, lane,
+                                                      FULL ? S : (int)(left < S ? (left < 0 ? 0 : left) : S));
+                    wave_lds_sync();
+                    continue;
+                }
                 // the round's S*91 values are one contiguous, 16-byte aligned block of j_ion
                 JT* jbase;
                 if constexpr (JMODE == 2) jbase = io.j_ion_f32; else jbase = io.j_ion;
@@ -518,6 +625,11 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
                         if (lane < rest) dst[pieces * PER16 + lane] = tile[pieces * PER16 + lane];
                     }
                 }
+                if constexpr (JMODE == 4) {             // the stores are on their way (their LDS reads are done): count the tile
+                    const long long left = io.n - first;
+                    qc.cnt = count_round<NQ, S, FULL>(qc.tab_off, qc.below_off, m.tile_off, qc.rec, qc.cap, qc.cnt, lane,
+                                                      FULL ? S : (int)(left < S ? (left < 0 ? 0 : left) : S));
+                }
                 wave_lds_sync();
             }
         }
@@ -539,6 +651,12 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
     // ------------------------------ EPILOGUE: one lane per sample ------------------------------
     double cos_div = num / den;  // plume.py:124-127
     if (cos_div == __builtin_inf()) cos_div = __builtin_nan("");
+    if constexpr (JMODE == 4 || JMODE == 5) {
+        // A NaN in a column makes its percentiles NaN, and the counting above never looks for one: any non-finite f_k leaves the
+        // Simpson sum non-finite (w_k f_k is NaN or infinite, and stays), a non-finite j_cex is seen directly -- such a sample
+        // (never under the priors) is reported and the selection falls back to the passes that examine every value.
+        if (live && (!__builtin_isfinite(den) || !__builtin_isfinite(j_cex))) atomicOr(io.q.flags + 1, 1);
+    }
     if constexpr (JMODE == 3) {
         if (live) io.loglik[g] = params[(2 * L) * WAVE + lane];
     }
@@ -567,10 +685,16 @@ struct NoDesign {};
 template <bool MC>
 using DesignArg = typename std::conditional<MC, McDesign, NoDesign>::type;
 
-template <int L, bool COUPLED, int JMODE, bool MC = false>
+// bytes of LDS the counting modes add per workgroup: brackets' {loh, words} [91][NQ] | below counters [NQ][91]
+template <int NQ>
+constexpr int count_lds_bytes() { return NANG * NQ * 8 + NQ * NANG * 4; }
+
+template <int L, bool COUPLED, int JMODE, bool MC = false, int NQ = 0>
 __global__ __launch_bounds__(WAVE * WPB) __attribute__((amdgpu_waves_per_eu(min_waves_per_simd<JMODE, MC>())))
 void plume_r1_kernel(PlumeIO io, CoupledIO cio, long long ntiles, DesignArg<MC> mc) {
     static_assert(!MC || COUPLED, "the fused Monte-Carlo mode generates the coupled inputs");
+    static_assert((JMODE == 4 || JMODE == 5) == (NQ > 0), "the counting modes, and only they, know their number of brackets");
+    static_assert(NQ == 0 || L == 4, "count_round keeps one bit per sample of a 16-sample round");
     static_assert(L == 2 || L == 4 || L == 8, "lanes per sample");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* lds = reinterpret_cast<double*>(smem_raw);
@@ -582,6 +706,7 @@ void plume_r1_kernel(PlumeIO io, CoupledIO cio, long long ntiles, DesignArg<MC> 
     m.poly = tab_poly;
     m.params = lds + TABLE_DOUBLES + wave * wave_lds_doubles<L, JMODE>();   // [rows][64], private to this wave
     m.tile = m.params + param_rows<L>() * WAVE;                               // [S*91] + sink
+    m.tile_off = (unsigned)(reinterpret_cast<unsigned char*>(m.tile) - smem_raw);
     m.qpoly = nullptr;
     if constexpr (JMODE == 0) {   // Simpson-functional tables behind the per-wave regions
         double* q = lds + TABLE_DOUBLES + WPB * wave_lds_doubles<L, JMODE>();
@@ -590,7 +715,7 @@ void plume_r1_kernel(PlumeIO io, CoupledIO cio, long long ntiles, DesignArg<MC> 
     }
     double* design = nullptr;
     if constexpr (MC) {   // the Monte-Carlo design behind everything else
-        static_assert(!MC || JMODE == 0 || JMODE == 1, "the fused Monte-Carlo mode writes an fp64 profile or none");
+        static_assert(!MC || JMODE == 0 || JMODE == 1 || JMODE == 4 || JMODE == 5, "the fused Monte-Carlo mode writes an fp64 profile or none");
         design = lds + TABLE_DOUBLES + WPB * wave_lds_doubles<L, JMODE>() + (JMODE == 0 ? QPOLY_DOUBLES : 0);
         if (tid < 15) {
             design[tid] = mc.a[tid];
@@ -613,10 +738,29 @@ void plume_r1_kernel(PlumeIO io, CoupledIO cio, long long ntiles, DesignArg<MC> 
         m.meas = meas;
     }
 
+    using QC = typename std::conditional<(NQ > 0), QCount, NoCount>::type;
+    QC qc;
+    if constexpr (NQ > 0) {   // the brackets and the below counters behind everything else
+        double* qbase = lds + TABLE_DOUBLES + WPB * wave_lds_doubles<L, JMODE>() + (MC ? MC_LDS_DOUBLES : 0);
+        uint2* qtab = reinterpret_cast<uint2*>(qbase);
+        unsigned* qbelow = reinterpret_cast<unsigned*>(qtab + NANG * NQ);
+        for (int i = tid; i < NANG * NQ; i += WAVE * WPB) {
+            // (a selection of fewer than NQ quantiles leaves the other brackets empty: loh = 2^32 - 1, no words)
+            const int c = i / NQ, q = i - c * NQ;
+            qtab[i] = q < io.q.nq ? make_uint2(io.q.br[c * io.q.nq + q].loh, io.q.br[c * io.q.nq + q].words) : make_uint2(0xffffffffu, 0u);
+            qbelow[i] = 0;
+        }
+        const unsigned gw = blockIdx.x * WPB + wave;
+        qc.tab_off = (unsigned)(reinterpret_cast<unsigned char*>(qtab) - smem_raw);
+        qc.below_off = (unsigned)(reinterpret_cast<unsigned char*>(qbelow) - smem_raw);
+        qc.rec = io.q.rec + (size_t)gw * io.q.cap;
+        qc.cap = io.q.cap;
+        qc.cnt = 0;
+    }
     for (int i = tid; i < NSIMP; i += WAVE * WPB)
         tab_simpson[i] = i < NANG ? make_double2(PEM_SIMPSON_CDEN[i], PEM_SIMPSON_CNUM[i]) : make_double2(0.0, 0.0);
     for (int i = tid; i < PEM_NDI * PEM_NDC; i += WAVE * WPB) tab_poly[i] = PEM_DPOLY[i];
-    __syncthreads();   // the only workgroup barrier: from here on the waves are independent
+    __syncthreads();   // the only workgroup barrier of the evaluation: from here on the waves are independent
 
     const double rad = io.radius;
     const double inv_r2 = 1.0 / (rad * rad);
@@ -640,14 +784,14 @@ void plume_r1_kernel(PlumeIO io, CoupledIO cio, long long ntiles, DesignArg<MC> 
     if constexpr (MC) {
         for (; t < nfull; t += nwaves) {
             const SampleIn<COUPLED> in = generate_sample(mc, design, t * WAVE + lane);
-            process_tile<L, COUPLED, JMODE, true>(io, cio, m, in, t, lane, rad, inv_r2, inv_2pi_r2);
+            process_tile<L, COUPLED, JMODE, true, NQ>(io, cio, m, in, t, lane, rad, inv_r2, inv_2pi_r2, qc);
         }
         if (nfull < ntiles && (nfull % nwaves) == me) {
             const long long g = nfull * WAVE + lane;
             McDesign quiet = mc;
             if (g >= io.n) quiet.x_out = nullptr;       // dead lanes recompute the last sample and store nothing
             const SampleIn<COUPLED> in = generate_sample(quiet, design, g < io.n ? g : io.n - 1);
-            process_tile<L, COUPLED, JMODE, false>(io, cio, m, in, nfull, lane, rad, inv_r2, inv_2pi_r2);
+            process_tile<L, COUPLED, JMODE, false, NQ>(io, cio, m, in, nfull, lane, rad, inv_r2, inv_2pi_r2, qc);
         }
     } else {
         if (t < nfull) {
@@ -655,14 +799,27 @@ void plume_r1_kernel(PlumeIO io, CoupledIO cio, long long ntiles, DesignArg<MC> 
             for (; t < nfull; t += nwaves) {
                 const SampleIn<COUPLED> in = nxt;
                 if (t + nwaves < nfull) nxt = load_sample<COUPLED>(io, cio, (t + nwaves) * WAVE + lane);
-                process_tile<L, COUPLED, JMODE, true>(io, cio, m, in, t, lane, rad, inv_r2, inv_2pi_r2);
+                process_tile<L, COUPLED, JMODE, true, NQ>(io, cio, m, in, t, lane, rad, inv_r2, inv_2pi_r2, qc);
             }
         }
         // the ragged last tile (n % 64 samples) goes to the wave that would have been next in line for it
         if (nfull < ntiles && (nfull % nwaves) == me) {
             const long long g = nfull * WAVE + lane;
             const SampleIn<COUPLED> in = load_sample<COUPLED>(io, cio, g < io.n ? g : io.n - 1);
-            process_tile<L, COUPLED, JMODE, false>(io, cio, m, in, nfull, lane, rad, inv_r2, inv_2pi_r2);
+            process_tile<L, COUPLED, JMODE, false, NQ>(io, cio, m, in, nfull, lane, rad, inv_r2, inv_2pi_r2, qc);
+        }
+    }
+    if constexpr (NQ > 0) {
+        // every wave reaches this barrier (no path above returns): the workgroup's counters are complete, one atomic each
+        if (lane == 0) {
+            io.q.rec_count[blockIdx.x * WPB + wave] = qc.cnt;
+            if (qc.cnt > qc.cap) atomicOr(io.q.flags, 1);
+        }
+        __syncthreads();
+        for (int i = tid; i < NQ * NANG; i += WAVE * WPB) {
+            const int q = i / NANG, c = i - q * NANG;
+            const unsigned v = reinterpret_cast<const unsigned*>(smem_raw + qc.below_off)[i];
+            if (v && q < io.q.nq) atomicAdd(&io.q.below[c * io.q.nq + q], (unsigned long long)v);
         }
     }
 }
@@ -1508,9 +1665,10 @@ int fast_grid(long long per_cu, long long ntiles, bool memory_bound, unsigned* g
     return PEM_OK;
 }
 
-template <int L, int JMODE, bool MC>
+template <int L, int JMODE, bool MC, int NQ = 0>
 size_t r1_lds_bytes(const PlumeIO& io) {
     size_t lds = (size_t)fast_lds_doubles<L, JMODE>() * 8;
+    if (NQ > 0) lds += (size_t)count_lds_bytes<(NQ > 0 ? NQ : 1)>();
     if (JMODE == 3) lds += (size_t)io.n_cond * (io.n_ang | 1) * 32;
     if (JMODE == 0) lds += (size_t)QPOLY_DOUBLES * 8;
     if (MC) lds += (size_t)MC_LDS_DOUBLES * 8;
@@ -1522,9 +1680,9 @@ size_t r1_lds_bytes(const PlumeIO& io) {
 // waits for a slot turns the tile split into a two-pass schedule -- and capped at two waves per SIMD, which measured
 // best for the HBM-bound modes, three for the profile-less ones: the fused Monte-Carlo kernel uses a third wave to
 // hide Philox's quarter-rate multiplies whenever its register count allows one (<= 168).
-template <int L, bool COUPLED, int JMODE, bool MC>
+template <int L, bool COUPLED, int JMODE, bool MC, int NQ = 0>
 int r1_per_cu(size_t lds, long long* per_cu) {
-    auto kern = plume_r1_kernel<L, COUPLED, JMODE, MC>;
+    auto kern = plume_r1_kernel<L, COUPLED, JMODE, MC, NQ>;
     // the register count belongs to the code object (one architecture): once per process
     static std::once_flag once;
     static int by_regs = 0;
@@ -1548,19 +1706,25 @@ int r1_per_cu(size_t lds, long long* per_cu) {
     return PEM_OK;
 }
 
-template <int L, bool COUPLED, int JMODE, bool MC = false>
-int launch_r1(const PlumeIO& io, const CoupledIO& cio, hipStream_t st, const McDesign& mc = McDesign{}) {
-    const size_t lds = r1_lds_bytes<L, JMODE, MC>(io);
+// `grid_only`: report the grid the launch would use (the counting modes size their record buffer by it) and launch nothing
+template <int L, bool COUPLED, int JMODE, bool MC = false, int NQ = 0>
+int launch_r1(const PlumeIO& io, const CoupledIO& cio, hipStream_t st, const McDesign& mc = McDesign{}, unsigned* grid_only = nullptr) {
+    const size_t lds = r1_lds_bytes<L, JMODE, MC, NQ>(io);
     const long long ntiles = (io.n + WAVE - 1) / WAVE;
     unsigned grid = 0;
-    auto kern = plume_r1_kernel<L, COUPLED, JMODE, MC>;
+    auto kern = plume_r1_kernel<L, COUPLED, JMODE, MC, NQ>;
     if (lds > 64 * 1024) {
         static pem::LdsAttrOnce attr;
         HIP_TRY(attr.ensure(reinterpret_cast<const void*>(kern)));
     }
     long long per_cu = 0;
-    if (int rc = r1_per_cu<L, COUPLED, JMODE, MC>(lds, &per_cu)) return rc;
+    if (int rc = r1_per_cu<L, COUPLED, JMODE, MC, NQ>(lds, &per_cu)) return rc;
+    // (the counting modes: a persistent grid of resident waves, each with its own region of the record buffer)
     if (int rc = fast_grid(per_cu, ntiles, JMODE == 1 || JMODE == 2, &grid)) return rc;
+    if (grid_only) {
+        *grid_only = grid;
+        return PEM_OK;
+    }
     if constexpr (MC) hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * WPB), lds, st, io, cio, ntiles, mc);
     else hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * WPB), lds, st, io, cio, ntiles, NoDesign{});
     HIP_TRY(hipGetLastError());
@@ -2002,6 +2166,148 @@ int pem_coupled_mc_f64_dev(size_t n, uint64_t first_index, uint64_t seed, uint32
     CoupledIO cio{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, V_cc, I_B0, T};
     hipStream_t st = static_cast<hipStream_t>(stream);
     return j_ion ? launch_r1<4, true, 1, true>(io, cio, st, mc) : launch_r1<4, true, 0, true>(io, cio, st, mc);
+}
+
+// ---- coupled, fused Monte-Carlo + campaign statistics: see csrc/pem_qfused.h, pem_coupled_mc_stats_f64_dev below --------------
+}  // extern "C"
+
+namespace {
+
+int mc_design_of(const pem::McLaunch& a, McDesign* mc) {
+    mc->seed = a.seed;
+    mc->first = a.first_index;
+    mc->stream = a.stream_id;
+    mc->swap_dim = -1;
+    for (int d = 0; d < 15; ++d) {
+        if (a.kind[d] < PEM_DIST_UNIFORM || a.kind[d] > PEM_DIST_NORMAL)
+            return fail(PEM_ERR_INVALID_ARG, "pem_coupled_mc: unknown distribution kind %d for input %d", a.kind[d], d);
+        mc->kind[d] = a.kind[d];
+        mc->a[d] = a.a[d];
+        mc->b[d] = a.b[d];
+    }
+    mc->x_out = a.x_out;
+    mc->ld = a.ld;
+    return PEM_OK;
+}
+
+// the counting launch for nq quantiles: instantiated for 3, 5 and 6 brackets per angle (fewer are padded with empty ones)
+template <int JMODE>
+int launch_count(const PlumeIO& io, const CoupledIO& cio, const McDesign& mc, int nq, hipStream_t st, unsigned* grid_only) {
+    if (nq <= 3) return launch_r1<4, true, JMODE, true, 3>(io, cio, st, mc, grid_only);
+    if (nq <= 5) return launch_r1<4, true, JMODE, true, 5>(io, cio, st, mc, grid_only);
+    return launch_r1<4, true, JMODE, true, 6>(io, cio, st, mc, grid_only);
+}
+
+}  // namespace
+
+namespace pem {
+
+int launch_coupled_mc(const McLaunch& a, hipStream_t st) {
+    if (a.n == 0) return PEM_OK;
+    McDesign mc{};
+    if (int rc = mc_design_of(a, &mc)) return rc;
+    PlumeIO io{(long long)a.n, a.torr2pa, a.radius, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, a.j_ion, a.div_angle, a.T_c, a.invalid, nullptr};
+    CoupledIO cio{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, a.V_cc, a.I_B0, a.T};
+    return a.j_ion ? launch_r1<4, true, 1, true>(io, cio, st, mc) : launch_r1<4, true, 0, true>(io, cio, st, mc);
+}
+
+static int count_launch(const McLaunch& a, const CountIO& c, bool store_profile, hipStream_t st, unsigned* grid_only) {
+    McDesign mc{};
+    if (int rc = mc_design_of(a, &mc)) return rc;
+    PlumeIO io{(long long)a.n, a.torr2pa, a.radius, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, a.j_ion, a.div_angle, a.T_c, a.invalid, nullptr};
+    io.q = c;
+    CoupledIO cio{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, a.V_cc, a.I_B0, a.T};
+    return store_profile ? launch_count<4>(io, cio, mc, c.nq, st, grid_only) : launch_count<5>(io, cio, mc, c.nq, st, grid_only);
+}
+
+int coupled_count_waves(size_t n, int nq, bool store_profile, unsigned* waves) {
+    McLaunch a{};
+    a.n = n;
+    for (int d = 0; d < 15; ++d) a.kind[d] = PEM_DIST_UNIFORM;
+    CountIO c{};
+    c.nq = nq;
+    unsigned grid = 0;
+    if (int rc = count_launch(a, c, store_profile, nullptr, &grid)) return rc;
+    *waves = grid * WPB;
+    return PEM_OK;
+}
+
+int launch_coupled_mc_count(const McLaunch& a, const CountIO& c, bool store_profile, hipStream_t st) {
+    if (a.n == 0) return PEM_OK;
+    if (c.nq < 1 || c.nq > 6 || !c.br || !c.below || !c.rec || !c.rec_count || !c.flags || c.cap == 0)
+        return fail(PEM_ERR_INVALID_ARG, "counting launch: incomplete arguments");
+    if (store_profile && !a.j_ion) return fail(PEM_ERR_INVALID_ARG, "counting launch: no profile array to store into");
+    return count_launch(a, c, store_profile, st, nullptr);
+}
+
+}  // namespace pem
+
+extern "C" {
+
+// ---- coupled, fused Monte-Carlo with the percentiles of the profile counted on the way (round 4) --------------------------------
+namespace {
+struct McProducer : pem::FusedProducer {
+    pem::McLaunch a;
+    bool store_profile;
+    int pilot(size_t rows, double* dst, hipStream_t st) override {
+        pem::McLaunch p = a;                       // samples 0 .. rows-1 of the same design; their profile rows go to dst
+        p.n = rows;
+        p.j_ion = dst;
+        return pem::launch_coupled_mc(p, st);
+    }
+    int waves(int nq, unsigned* w) override { return pem::coupled_count_waves(a.n, nq, store_profile, w); }
+    int count(const pem::CountIO& io, hipStream_t st) override { return pem::launch_coupled_mc_count(a, io, store_profile, st); }
+};
+}  // namespace
+
+int pem_coupled_mc_stats_f64_dev(size_t n, uint64_t first_index, uint64_t seed, uint32_t stream_id, const int32_t* kind, const double* a,
+                                 const double* b, double torr2pa, double radius, double* x_out, size_t ld, double* V_cc, double* I_B0,
+                                 double* T, double* j_ion, double* pilot_rows, double* div_angle, double* T_c, uint8_t* invalid, int nq,
+                                 const uint64_t* rank_prev, const uint64_t* rank_next, const double* gamma, double* q_out, int* fused_ok,
+                                 pem_stream_t stream) {
+    if (!kind || !a || !b || !V_cc || !div_angle || !T_c || !rank_prev || !rank_next || !gamma || !q_out || !fused_ok)
+        return fail(PEM_ERR_INVALID_ARG, "pem_coupled_mc_stats: NULL array");
+    if (!j_ion && !pilot_rows) return fail(PEM_ERR_INVALID_ARG, "pem_coupled_mc_stats: without a profile array, room for the pilot rows is needed");
+    if (j_ion && !aligned16(j_ion)) return fail(PEM_ERR_INVALID_ARG, "pem_coupled_mc_stats: j_ion must be 16-byte aligned");
+    if (pilot_rows && !aligned16(pilot_rows)) return fail(PEM_ERR_INVALID_ARG, "pem_coupled_mc_stats: pilot_rows must be 16-byte aligned");
+    if (x_out && ld < n) return fail(PEM_ERR_INVALID_ARG, "pem_coupled_mc_stats: leading dimension smaller than n");
+    if (nq < 1 || nq > PEM_QUANTILE_MAX_Q) return fail(PEM_ERR_INVALID_ARG, "pem_coupled_mc_stats: 1 <= nq <= %d", PEM_QUANTILE_MAX_Q);
+    if (n < PEM_MC_STATS_MIN_N) return fail(PEM_ERR_INVALID_ARG, "pem_coupled_mc_stats: at least %d samples", PEM_MC_STATS_MIN_N);
+    if (int rc = check_device()) return rc;
+    McProducer prod;
+    prod.a.n = n;
+    prod.a.first_index = first_index;
+    prod.a.seed = seed;
+    prod.a.stream_id = stream_id;
+    for (int d = 0; d < 15; ++d) {
+        prod.a.kind[d] = kind[d];
+        prod.a.a[d] = a[d];
+        prod.a.b[d] = b[d];
+    }
+    prod.a.torr2pa = torr2pa;
+    prod.a.radius = radius;
+    prod.a.x_out = x_out;
+    prod.a.ld = ld;
+    prod.a.V_cc = V_cc;
+    prod.a.I_B0 = I_B0;
+    prod.a.T = T;
+    prod.a.j_ion = j_ion;
+    prod.a.div_angle = div_angle;
+    prod.a.T_c = T_c;
+    prod.a.invalid = invalid;
+    prod.store_profile = j_ion != nullptr;
+    *fused_ok = 0;
+    // with a profile array the pilot rows are its own first rows (the counting launch writes the same values there again)
+    if (int rc = pem::quantiles_fused(n, NANG, nq, rank_prev, rank_next, gamma, j_ion ? j_ion : pilot_rows, prod, q_out, fused_ok,
+                                      static_cast<hipStream_t>(stream)))
+        return rc;
+    if (!*fused_ok) {
+        // declined -- possibly before the counting launch, with nothing but the pilot's samples evaluated: the plain launch makes
+        // every output complete (a rare path: 1.5 ms per 1e7 samples where the counting launch had already run)
+        if (int rc = pem::launch_coupled_mc(prod.a, static_cast<hipStream_t>(stream))) return rc;
+        HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    }
+    return PEM_OK;
 }
 
 // ---- coupled + likelihood fused: the profile never leaves the chip ------------------------------------------------

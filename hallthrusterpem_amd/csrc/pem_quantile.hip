@@ -29,6 +29,7 @@
 
 #include "pem_common.h"
 #include "pem_hip.h"
+#include "pem_qfused.h"
 
 namespace {
 
@@ -631,43 +632,60 @@ __global__ void finish_kernel(int m, int nq, const Column* __restrict__ col, con
 // (below <= rank < below + inside), and if any does not -- data ordered so that the strided rows misrepresent it -- the call
 // falls back to the four passes.  The subsample only decides how often that happens: with brackets 7 sigma wide, for
 // exchangeable rows (Monte-Carlo, Latin hypercube and Saltelli designs), about once in 1e9 calls.
-struct Bracket {         // per (column, quantile)
-    u64 lo, span;        // keys lo .. lo + span
-    unsigned mult;       // floor(2^32 bins / ((span >> shift) + 1)), as Column
-    int shift;
-};
+using pem::Bracket;     // per (column, quantile): the keys lo .. hi, binned on their HIGH WORDS (round 4; csrc/pem_qfused.h)
+// Binning inside a bracket (round 4).  The counting pass met a value of SOME bracket in nearly every wave instruction (64 lanes
+// x nq brackets x 1.3 %), so whatever a value inside a bracket costs, every value paid: with the sub-bin taken from the 64-bit
+// offset k - lo (subtract, shift, quarter-rate multiply, per bracket) three quantiles ran at 1.35 ms per 1e7 x 91 and five at
+// 3.0 ms -- instruction issue, not memory.  The sub-bin is now a function of the key's high word alone: t = kh - loh,
+// bin = floor(t mult / 2^32) -- never decreasing with the key, so still a valid binning -- which a lane gets from the
+// subtraction that also tells it whether the value lies below the bracket (the borrow) or inside (t <= words).  Only a key whose
+// high word EQUALS that of lo or hi (one value in 1e5) is compared in full.  A bracket narrower than `bins` high words -- a
+// column with a relative spread below 1e-5 -- puts several sub-bins' worth of values into one list; select_from narrows such a
+// list by histograms of its own, as it does for ties.
 struct PilotEnds {       // a bracket end that would lie outside the subsample is open: the smallest / largest key
     int open_lo[PEM_QUANTILE_MAX_Q], open_hi[PEM_QUANTILE_MAX_Q];
 };
 
-// brackets from the order statistics of the subsample (targets 2q, 2q + 1 of the pilot run: the lower and the upper end)
-__global__ void brackets_kernel(int m, int nq, const Target* __restrict__ ptg, PilotEnds e, int bins, Bracket* __restrict__ br) {
+// brackets from the order statistics of the subsample (targets 2q, 2q + 1 of the pilot run: the lower and the upper end).
+// The ends are moved outwards to whole high words -- lo to the first key of its word, hi to the last key of its -- so that
+// "below", "inside" and the sub-bin are all functions of a key's high word: any interval that holds the wanted ranks will do,
+// and this one is at most two parts in a million wider.  The exception is a bracket whose ends are ONE key (the subsample's
+// order statistics coincide: a constant column, or heavy ties such as the 1e-20 profile of invalid samples): it stays that key,
+// is counted by comparing whole keys (mult = 0 marks it; `any_single` tells the counting pass to take its general loop) and
+// answers its ranks without a list.
+__global__ void brackets_kernel(int m, int nq, const Target* __restrict__ ptg, PilotEnds e, int bins, Bracket* __restrict__ br,
+                                int* __restrict__ any_single) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m * nq) return;
     const int c = i / nq, q = i - c * nq;
-    const u64 lo = e.open_lo[q] ? 0ull : ptg[c * 2 * nq + 2 * q].answer;
+    u64 lo = e.open_lo[q] ? 0ull : ptg[c * 2 * nq + 2 * q].answer;
     u64 hi = e.open_hi[q] ? ~0ull : ptg[c * 2 * nq + 2 * q + 1].answer;
     if (hi < lo) hi = lo;                  // (a subsample column without a finite value: the column's result is NaN anyway)
     Bracket b;
+    const bool single = lo == hi;
+    if (!single) {
+        lo &= 0xffffffff00000000ull;
+        hi |= 0x00000000ffffffffull;
+    }
     b.lo = lo;
-    b.span = hi - lo;
-    int shift = 0;
-    while ((b.span >> shift) >> 31) ++shift;
-    const u64 mult = (((u64)bins) << 32) / ((b.span >> shift) + 1);
-    b.shift = shift;
-    b.mult = mult > 0xffffffffull ? 0xffffffffu : (unsigned)mult;
+    b.hi = hi;
+    b.loh = (unsigned)(lo >> 32);
+    b.words = (unsigned)(hi >> 32) - b.loh;
+    const u64 mult = (((u64)bins) << 32) / ((u64)b.words + 1);
+    b.mult = single ? 0u : (mult > 0xffffffffull ? 0xffffffffu : (unsigned)mult);
+    b.pad = 0;
     br[i] = b;
+    if (single) atomicExch(any_single, 1);
 }
 
-__device__ __forceinline__ int bracket_bin(u64 d, unsigned mult, int shift) { return (int)(((u64)(unsigned)(d >> shift) * mult) >> 32); }
 // the high word of key_of(x) from the high word of x alone (three instructions; the passes below decide nearly every value on it)
 __device__ __forceinline__ unsigned key_high(double x) {
     const int bh = __double2hiint(x);
     return (unsigned)bh ^ ((unsigned)(bh >> 31) | 0x80000000u);
 }
-// the smallest d in [0, D + 1] whose bin is >= b (D + 1: none) -- the binning is monotone, so this is where sub-bin b begins
-__device__ __forceinline__ u64 first_d_of_bin(unsigned mult, int b, u64 D) {
-    u64 lo = 0, hi = D + 1;
+// the smallest t in [0, words + 1] whose bin is >= b (words + 1: none) -- the binning is monotone, so this is where sub-bin b begins
+__device__ __forceinline__ u64 first_t_of_bin(unsigned mult, int b, unsigned words) {
+    u64 lo = 0, hi = (u64)words + 1;
     while (lo < hi) {
         const u64 mid = (lo + hi) >> 1;
         if ((int)((mid * mult) >> 32) >= b) hi = mid;
@@ -677,23 +695,22 @@ __device__ __forceinline__ u64 first_d_of_bin(unsigned mult, int b, u64 D) {
 }
 
 // pass A: per (column, quantile) the number of values below the bracket and a histogram of those inside it; NaN per column
-// Up to 128 columns two workgroups share a CU (16 waves: the pass is as much instruction issue as memory): the bracket histogram
-// gets half the LDS (LDS_WORDS_A) and the registers have to fit twice; four columns per lane need them all.
+// Up to 128 columns and three quantiles two workgroups share a CU (16 waves): the bracket histogram gets half the LDS (LDS_WORDS_A)
+// and the registers have to fit twice; four columns per lane, or more quantiles, take a CU each.
 constexpr int LDS_WORDS_A = 20224;        // 79 KB of 32-bit counters per workgroup
 template <int NC, int NQ>
-constexpr int bracket_waves_per_simd() { return (NC <= 2 && NQ <= 3) ? 4 : 2; }
+constexpr int bracket_waves_per_simd() { return NC <= 2 ? 4 : 2; }
 template <int NC, int NQ>
 __global__ __launch_bounds__(QBLOCK) __attribute__((amdgpu_waves_per_eu(bracket_waves_per_simd<NC, NQ>()))) void bracket_hist_kernel(long long n, int m, size_t ld, size_t cs, const double* __restrict__ data,
-                                                               const Bracket* __restrict__ br, int bins, Column* __restrict__ col,
-                                                               u64* __restrict__ below, unsigned* __restrict__ hist) {
+                                                               const Bracket* __restrict__ br, const int* __restrict__ any_single, int bins,
+                                                               Column* __restrict__ col, u64* __restrict__ below, unsigned* __restrict__ hist) {
     extern __shared__ unsigned lds_hist[];                      // [m][NQ][bins] | below [m][NQ]
     unsigned* lds_below = lds_hist + m * NQ * bins;
     for (int i = threadIdx.x; i < m * NQ * (bins + 1); i += QBLOCK) lds_hist[i] = 0;
     __syncthreads();
     const Lanes L(m, threadIdx.x & 63, cs);
-    u64 blo[NC][NQ], bspan[NC][NQ];
-    unsigned bmult[NC][NQ], nbelow[NC][NQ], bwords[NC][NQ];
-    int bshift[NC][NQ], nan[NC];
+    unsigned bloh[NC][NQ], bwords[NC][NQ], bmult[NC][NQ], nbelow[NC][NQ];
+    int nan[NC];
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
         const int c = L.col0 + 64 * j;
@@ -701,40 +718,50 @@ __global__ __launch_bounds__(QBLOCK) __attribute__((amdgpu_waves_per_eu(bracket_
         nan[j] = 0;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            blo[j][q] = on ? br[c * NQ + q].lo : 0;
-            bspan[j][q] = on ? br[c * NQ + q].span : 0;
+            bloh[j][q] = on ? br[c * NQ + q].loh : 0;
+            bwords[j][q] = on ? br[c * NQ + q].words : 0;
             bmult[j][q] = on ? br[c * NQ + q].mult : 0;
-            bshift[j][q] = on ? br[c * NQ + q].shift : 0;
-            bwords[j][q] = (unsigned)((blo[j][q] + bspan[j][q]) >> 32) - (unsigned)(blo[j][q] >> 32);
             nbelow[j][q] = 0;
         }
     }
-    // Nearly every value lies outside every bracket, and the HIGH word of its key says so: per bracket a compare-and-count and
-    // a range test in 32 bits, no branch.  Only a key whose high word lies between those of a bracket's ends is looked at in
-    // full (about every other wave instruction holds one: 64 lanes x 3 brackets x 1 %).  A NaN is flagged and otherwise counted
-    // as whatever its bits say: the column's result is NaN whatever the counts are.
-    stream_values<NC>(n, m, ld, data, L, [&](int j, int c, double x) {
-        nan[j] |= x != x ? 1 : 0;
-        const unsigned kh = key_high(x);
-        bool near = false;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const unsigned loh = (unsigned)(blo[j][q] >> 32);
-            nbelow[j][q] += kh < loh ? 1u : 0u;
-            near |= kh - loh <= bwords[j][q];
-        }
-        if (near && x == x) {
-            const u64 k = key_of(x);
+    // Per value and bracket: one subtraction of high words -- its borrow says "below", its result t <= words says "inside" and is
+    // the sub-bin's argument; nothing else.  A NaN is flagged and otherwise counted as whatever its bits say: the column's result
+    // is NaN whatever the counts are.  The general loop (taken by every wave when some bracket is a single key) compares whole
+    // keys for those brackets.
+    if (*any_single == 0) {
+        stream_values<NC>(n, m, ld, data, L, [&](int j, int c, double x) {
+            const bool num = x == x;
+            nan[j] |= num ? 0 : 1;
+            const unsigned kh = key_high(x);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                if (kh - (unsigned)(blo[j][q] >> 32) <= bwords[j][q]) {
-                    const u64 d = k - blo[j][q];                // wraps above every span when k < lo (then kh == loh)
-                    nbelow[j][q] += k < blo[j][q] ? 1u : 0u;
-                    if (d <= bspan[j][q]) atomicAdd(&lds_hist[(c * NQ + q) * bins + bracket_bin(d, bmult[j][q], bshift[j][q])], 1u);
+                unsigned t;
+                nbelow[j][q] += __builtin_sub_overflow(kh, bloh[j][q], &t) ? 1u : 0u;
+                // (a borrow leaves t above every `words`: 2^32 - loh + kh > hih - loh)
+                if (t <= bwords[j][q] && num) atomicAdd(&lds_hist[(c * NQ + q) * bins + (int)__umulhi(t, bmult[j][q])], 1u);
+            }
+        });
+    } else {
+        stream_values<NC>(n, m, ld, data, L, [&](int j, int c, double x) {
+            const bool num = x == x;
+            nan[j] |= num ? 0 : 1;
+            const unsigned kh = key_high(x);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                unsigned t;
+                nbelow[j][q] += __builtin_sub_overflow(kh, bloh[j][q], &t) ? 1u : 0u;
+                if (t <= bwords[j][q] && num) {
+                    if (bmult[j][q] != 0) {
+                        atomicAdd(&lds_hist[(c * NQ + q) * bins + (int)__umulhi(t, bmult[j][q])], 1u);
+                    } else {                                    // a bracket of one key: its word holds keys below, equal and above
+                        const u64 k = key_of(x), only = br[c * NQ + q].lo;
+                        if (k < only) nbelow[j][q] += 1u;
+                        else if (k == only) atomicAdd(&lds_hist[(c * NQ + q) * bins], 1u);
+                    }
                 }
             }
-        }
-    });
+        });
+    }
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
         const int c = L.col0 + 64 * j;
@@ -781,7 +808,7 @@ __global__ __launch_bounds__(64) void decide_bracket_kernel(int nt, Column* __re
             T.done = 1;
             T.answer = 0;
             if (lane == 0) atomicExch(outside, 1);
-        } else if (b.span == 0) {          // a bracket of one key (a constant column): the answer is that key
+        } else if (b.lo == b.hi) {         // a bracket of one key (a constant column): the answer is that key
             T.done = 1;
             T.answer = b.lo;
         } else {
@@ -802,59 +829,138 @@ __global__ __launch_bounds__(QBLOCK) void compact_bracket_kernel(long long n, in
                                                                   u64* __restrict__ cand) {
     constexpr int NT = 2 * NQ;
     const Lanes L(m, threadIdx.x & 63, cs);
-    // per (column, quantile): the key range of the sub-bins its list owners collect (two adjacent ranks: one sub-bin, or two
-    // neighbours), found from the binning itself; a value is tested against its high words only
-    u64 rlo[NC][NQ], rspan[NC][NQ];
-    unsigned rwords[NC][NQ];
-    int tb2[NC][NT];
+    // per (column, quantile): the range of high words (as offsets t from the bracket's first) of the sub-bins its list owners
+    // collect (two adjacent ranks: one sub-bin, or two neighbours), found from the binning itself; a value is tested against it
+    // with one subtraction and one comparison
+    unsigned rloh[NC][NQ], rwords[NC][NQ];
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
         const int c = L.col0 + 64 * j;
         const bool on = L.active && c < m;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            u64 lo = ~0ull, hi = 0ull;
+            u64 lo = ~0ull, hi = 0ull;                          // as high words (64-bit so that "none" fits)
 #pragma unroll
             for (int t = 2 * q; t < 2 * q + 2; ++t) {
                 const bool own = on && !tg[c * NT + t].done && tg[c * NT + t].owner == t;   // only list owners collect
-                tb2[j][t] = own ? tg[c * NT + t].bin2 : -1;
                 if (own) {
                     const Bracket B = br[c * NQ + q];
-                    const u64 D = B.span >> B.shift;
-                    const u64 d0 = first_d_of_bin(B.mult, tb2[j][t], D), d1 = first_d_of_bin(B.mult, tb2[j][t] + 1, D);
-                    const u64 k0 = B.lo + (d0 << B.shift), k1 = d1 > D ? B.lo + B.span : B.lo + (d1 << B.shift) - 1;
-                    lo = k0 < lo ? k0 : lo;
-                    hi = k1 > hi ? k1 : hi;
+                    const int b2 = tg[c * NT + t].bin2;
+                    const u64 t0 = first_t_of_bin(B.mult, b2, B.words), t1 = first_t_of_bin(B.mult, b2 + 1, B.words);
+                    const u64 h0 = (u64)B.loh + t0, h1 = (u64)B.loh + (t1 > (u64)B.words ? (u64)B.words : t1 - 1);
+                    lo = h0 < lo ? h0 : lo;
+                    hi = h1 > hi ? h1 : hi;
                 }
             }
-            if (lo > hi) lo = hi = ~0ull;                       // no owner: a range no value's key lies in
-            rlo[j][q] = lo;
-            rspan[j][q] = hi - lo;
-            rwords[j][q] = (unsigned)(hi >> 32) - (unsigned)(lo >> 32);
+            if (lo > hi) {                                      // no owner: a range no high word lies in
+                rloh[j][q] = 0xffffffffu;
+                rwords[j][q] = 0u;
+            } else {
+                rloh[j][q] = (unsigned)lo;
+                rwords[j][q] = (unsigned)(hi - lo);
+            }
         }
     }
     stream_values<NC>(n, m, ld, data, L, [&](int j, int c, double x) {
         const unsigned kh = key_high(x);
         bool near = false;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) near |= kh - (unsigned)(rlo[j][q] >> 32) <= rwords[j][q];
+        for (int q = 0; q < NQ; ++q) near |= kh - rloh[j][q] <= rwords[j][q];
         if (near && x == x) {                                   // (about one wave instruction in ten)
             const u64 k = key_of(x);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                if (k - rlo[j][q] <= rspan[j][q]) {
+                if (kh - rloh[j][q] <= rwords[j][q]) {
                     const Bracket B = br[c * NQ + q];
-                    const int b = bracket_bin(k - B.lo, B.mult, B.shift);
-                    // (the two targets of a quantile share a list when they share the sub-bin: at most one of them owns it)
-                    const int hit = tb2[j][2 * q] == b ? 2 * q : (tb2[j][2 * q + 1] == b ? 2 * q + 1 : -1);
-                    if (hit >= 0) {
-                        Target& T = tg[c * NT + hit];
-                        cand[T.offset + atomicAdd(&T.cursor, 1ull)] = k;
+                    {                                           // (list owners' brackets end on whole words: the high word has decided)
+                        const int b = (int)__umulhi(kh - B.loh, B.mult);
+                        // (the two targets of a quantile share a list when they share the sub-bin: at most one of them owns it)
+                        const Target& T0 = tg[c * NT + 2 * q];
+                        const Target& T1 = tg[c * NT + 2 * q + 1];
+                        const int hit = (!T0.done && T0.owner == 2 * q && T0.bin2 == b) ? 2 * q
+                                        : ((!T1.done && T1.owner == 2 * q + 1 && T1.bin2 == b) ? 2 * q + 1 : -1);
+                        if (hit >= 0) {
+                            Target& T = tg[c * NT + hit];
+                            cand[T.offset + atomicAdd(&T.cursor, 1ull)] = k;
+                        }
                     }
                 }
             }
         }
     });
+}
+
+// ---- the fused form (round 4): counts and records come from the kernel that PRODUCES the array (csrc/pem_qfused.h) ------------
+// pass A's below-counts are already there; its histogram inside the brackets, and pass B's copy, run over the records -- the few
+// per cent of the values that lie inside a bracket -- instead of over the array.
+
+// a producer's counting launch assumes brackets that end on whole words (not a single key) and do not overlap within a column
+__global__ void bracket_check_kernel(int m, int nq, const Bracket* __restrict__ br, int* __restrict__ unfit) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m * nq) return;
+    const int c = i / nq, q = i - c * nq;
+    const Bracket b = br[i];
+    bool bad = b.mult == 0;
+    for (int u = 0; u < nq; ++u) {
+        if (u == q) continue;
+        const Bracket o = br[c * nq + u];
+        if ((u64)b.loh <= (u64)o.loh + o.words && (u64)o.loh <= (u64)b.loh + b.words) bad = true;
+    }
+    if (bad) atomicExch(unfit, 1);
+}
+
+constexpr int REC_LISTS_MAX = 64 * 2 * PEM_QUANTILE_MAX_Q;     // (column, quantile) pairs the record kernels keep a table of (m <= 128)
+
+__global__ __launch_bounds__(QBLOCK) void record_hist_kernel(const pem::Record* __restrict__ rec, const unsigned* __restrict__ rec_count, unsigned cap,
+                                                              unsigned waves, const Bracket* __restrict__ br, int lists, int bins,
+                                                              unsigned* __restrict__ hist) {
+    extern __shared__ unsigned lds_hist[];                      // [lists][bins]
+    __shared__ uint2 s_br[REC_LISTS_MAX];                       // {loh, mult}
+    for (int i = threadIdx.x; i < lists * bins; i += QBLOCK) lds_hist[i] = 0;
+    for (int i = threadIdx.x; i < lists; i += QBLOCK) s_br[i] = make_uint2(br[i].loh, br[i].mult);
+    __syncthreads();
+    for (unsigned w = blockIdx.x; w < waves; w += gridDim.x) {
+        const unsigned cnt = rec_count[w] < cap ? rec_count[w] : cap;
+        const pem::Record* r = rec + (size_t)w * cap;
+        for (unsigned i = threadIdx.x; i < cnt; i += QBLOCK) {
+            const pem::Record e = r[i];
+            const uint2 b = s_br[e.cq];
+            atomicAdd(&lds_hist[(int)e.cq * bins + (int)__umulhi((unsigned)(e.key >> 32) - b.x, b.y)], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < lists * bins; i += QBLOCK) {
+        const unsigned v = lds_hist[i];
+        if (v) atomicAdd(&hist[i], v);
+    }
+}
+
+__global__ __launch_bounds__(QBLOCK) void record_compact_kernel(const pem::Record* __restrict__ rec, const unsigned* __restrict__ rec_count, unsigned cap,
+                                                                 unsigned waves, const Bracket* __restrict__ br, int lists, Target* __restrict__ tg,
+                                                                 u64* __restrict__ cand) {
+    __shared__ uint2 s_br[REC_LISTS_MAX];                       // {loh, mult}
+    __shared__ int2 s_bin[REC_LISTS_MAX];                       // the sub-bins the quantile's two targets collect (-1: not a list owner)
+    for (int i = threadIdx.x; i < lists; i += QBLOCK) {
+        s_br[i] = make_uint2(br[i].loh, br[i].mult);
+        const Target &T0 = tg[2 * i], &T1 = tg[2 * i + 1];     // targets 2q, 2q + 1 of column c sit at (c nq + q) 2
+        s_bin[i] = make_int2((!T0.done && (T0.owner & 1) == 0) ? T0.bin2 : -1, (!T1.done && (T1.owner & 1) == 1) ? T1.bin2 : -1);
+    }
+    __syncthreads();
+    for (unsigned w = blockIdx.x; w < waves; w += gridDim.x) {
+        const unsigned cnt = rec_count[w] < cap ? rec_count[w] : cap;
+        const pem::Record* r = rec + (size_t)w * cap;
+        for (unsigned i = threadIdx.x; i < cnt; i += QBLOCK) {
+            const pem::Record e = r[i];
+            const uint2 b = s_br[e.cq];
+            const int bin = (int)__umulhi((unsigned)(e.key >> 32) - b.x, b.y);
+            const int2 want = s_bin[e.cq];
+            const int hit = want.x == bin ? 0 : (want.y == bin ? 1 : -1);
+            if (hit >= 0) {
+                Target& T = tg[2 * e.cq + hit];
+                cand[T.offset + atomicAdd(&T.cursor, 1ull)] = e.key;
+            }
+        }
+    }
 }
 
 // ---- the multi-rank form: histograms over caller-given key ranges -----------------------------------------------------------
@@ -966,9 +1072,15 @@ int pow2_at_most(long long x, int cap) {
 static std::atomic<int> g_last_path{0};
 extern "C" int pem_quantiles_last_path(void) { return g_last_path.load(); }
 
-extern "C" int pem_quantiles_strided_f64_dev(size_t n, int m, const double* data, size_t ld, size_t cs, int nq, const uint64_t* rank_prev,
-                                             const uint64_t* rank_next, const double* gamma, double* out, pem_stream_t stream) {
+// `fused` (with `fused_ok`): the array does not exist (yet) -- `data` are its first ceil(n / pilot) rows, written by the producer,
+// and pass A / pass B are the producer's counting launch and two passes over its records (csrc/pem_qfused.h).  *fused_ok = 0: the
+// brackets were unfit for the producer, a rank fell outside its bracket, or the producer reported an overflow or a non-finite
+// sample -- `out` is then not written and the caller takes the passes over the array itself.
+static int quantiles_impl(size_t n, int m, const double* data, size_t ld, size_t cs, int nq, const uint64_t* rank_prev,
+                          const uint64_t* rank_next, const double* gamma, double* out, pem_stream_t stream, pem::FusedProducer* fused,
+                          int* fused_ok) {
     if (m < 1 || m > 64 * MAX_NC) return pem::fail(PEM_ERR_INVALID_ARG, "pem_quantiles: 1 <= m <= %d columns", 64 * MAX_NC);
+    if (fused && (m > 128 || !fused_ok)) return pem::fail(PEM_ERR_INVALID_ARG, "pem_quantiles: the fused form takes up to 128 columns");
     if (cs < 1 || (cs == 1 ? ld < (size_t)m : (ld != 1 || cs < n)))
         return pem::fail(PEM_ERR_INVALID_ARG, "pem_quantiles: rows of m columns (column stride 1, ld >= m) or columns of n rows (ld 1, column stride >= n)");
     if (nq < 1 || nq > (m <= 128 ? PEM_QUANTILE_MAX_Q : PEM_QUANTILE_MAX_Q_WIDE))
@@ -983,7 +1095,8 @@ extern "C" int pem_quantiles_strided_f64_dev(size_t n, int m, const double* data
     const int nt = 2 * nq;
     const int bins1 = pow2_at_most(LDS_WORDS / m, 4096), bins2 = pow2_at_most(LDS_WORDS / (m * nt), 4096);
     // (four quantiles or more: the brackets' registers leave room for one workgroup per CU anyway -- it gets all of the LDS)
-    int binsA = pow2_at_most(((m <= 128 && nq <= 3) ? LDS_WORDS_A : LDS_WORDS) / (m * nq) - 1, 4096);   // the pilot form's histogram inside a bracket (+ 1 counter)
+    int binsA = pow2_at_most((m <= 128 ? LDS_WORDS_A : LDS_WORDS) / (m * nq) - 1, 4096);   // the pilot form's histogram inside a bracket (+ 1 counter)
+    if (fused) binsA = pow2_at_most(LDS_WORDS / (m * nq), 4096);          // (the record passes: one workgroup per CU with all of its LDS)
     if (const char* e = getenv("PEM_QUANTILE_BINSA")) binsA = pow2_at_most(atoll(e) < binsA ? atoll(e) : binsA, 4096);
 
     // the pilot form: every `pilot`-th row brackets the wanted ranks (PEM_QUANTILE_PILOT: the stride, 0 = never;
@@ -992,7 +1105,9 @@ extern "C" int pem_quantiles_strided_f64_dev(size_t n, int m, const double* data
     long long pilot = 32, pilot_min = 1 << 25;
     if (const char* e = getenv("PEM_QUANTILE_PILOT")) pilot = atoll(e);
     if (const char* e = getenv("PEM_QUANTILE_PILOT_MIN")) pilot_min = atoll(e);
-    const bool use_pilot = pilot >= 2 && (long long)n * m >= pilot_min && (long long)n >= 4 * pilot;
+    if (fused) pilot = 32;                                                // (the producer wrote rows 0 .. ceil(n / 32) - 1)
+    const bool use_pilot = fused ? true : (pilot >= 2 && (long long)n * m >= pilot_min && (long long)n >= 4 * pilot);
+    if (fused && (long long)n < 4 * pilot) return pem::fail(PEM_ERR_INVALID_ARG, "pem_quantiles: the fused form needs at least %lld rows", 4 * pilot);
 
     // workspace: columns | targets | hist1 | hist2 | total, outside | brackets | below | histA -- kept between calls (grow-only,
     // one per process; calls are serialised on it, and each one ends with a stream synchronisation before the next may touch it)
@@ -1001,11 +1116,16 @@ extern "C" int pem_quantiles_strided_f64_dev(size_t n, int m, const double* data
     const size_t b_br = sizeof(Bracket) * m * nq, b_bl = sizeof(u64) * m * nq, b_hA = sizeof(unsigned) * (size_t)m * nq * binsA;
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t o_tg = up(b_col), o_h1 = o_tg + up(b_tg), o_h2 = o_h1 + up(b_h1), o_tot = o_h2 + up(b_h2);
-    const size_t o_br = o_tot + 256, o_bl = o_br + up(b_br), o_hA = o_bl + up(b_bl), o_end = o_hA + up(b_hA);
+    unsigned fused_waves = 0;
+    if (fused)
+        if (int rc = fused->waves(nq, &fused_waves)) return rc;
+    const size_t b_rc = sizeof(unsigned) * fused_waves;
+    const size_t o_br = o_tot + 256, o_bl = o_br + up(b_br), o_hA = o_bl + up(b_bl), o_rc = o_hA + up(b_hA), o_end = o_rc + up(b_rc);
     static std::mutex mu;
     static char* ws_buf = nullptr;
-    static size_t ws_cap = 0, cand_cap = 0;
+    static size_t ws_cap = 0, cand_cap = 0, rec_cap = 0;
     static u64* cand_buf = nullptr;
+    static pem::Record* rec_buf = nullptr;
     static int ws_dev = -1;
     std::lock_guard<std::mutex> lock(mu);
     int dev = 0;
@@ -1016,6 +1136,11 @@ extern "C" int pem_quantiles_strided_f64_dev(size_t n, int m, const double* data
             (void)hipFree(cand_buf);
             cand_buf = nullptr;
             cand_cap = 0;
+        }
+        if (rec_buf && dev != ws_dev) {
+            (void)hipFree(rec_buf);
+            rec_buf = nullptr;
+            rec_cap = 0;
         }
         ws_buf = nullptr;
         ws_cap = 0;
@@ -1030,7 +1155,11 @@ extern "C" int pem_quantiles_strided_f64_dev(size_t n, int m, const double* data
     unsigned* hist2 = reinterpret_cast<unsigned*>(ws + o_h2);
     u64* total = reinterpret_cast<u64*>(ws + o_tot);                       // total[0]: candidates; total[1] (as int): a rank outside its bracket
     int* outside = reinterpret_cast<int*>(total + 1);
-    int* incomplete = reinterpret_cast<int*>(total + 2);                   // a list shorter or longer than counted (select_kernel)
+    int* incomplete = reinterpret_cast<int*>(total + 2);                   // a list shorter or longer than counted (select_kernel), 4 words
+    int* any_single = reinterpret_cast<int*>(total + 8);                   // a bracket of one key exists (brackets_kernel)
+    int* unfit = reinterpret_cast<int*>(total + 9);                        // fused form: brackets a producer cannot count against
+    int* prod_flags = reinterpret_cast<int*>(total + 10);                  // fused form: the producer's overflow / non-finite flags (2 ints)
+    unsigned* rec_count = reinterpret_cast<unsigned*>(ws + o_rc);
     Bracket* br = reinterpret_cast<Bracket*>(ws + o_br);
     u64* below = reinterpret_cast<u64*>(ws + o_bl);
     unsigned* histA = reinterpret_cast<unsigned*>(ws + o_hA);
@@ -1166,24 +1295,75 @@ extern "C" int pem_quantiles_strided_f64_dev(size_t n, int m, const double* data
             pw.prev[q] = ends.open_lo[q] ? 0 : (u64)r_lo;
             pw.next[q] = ends.open_hi[q] ? (u64)(rows_p - 1) : (u64)r_hi;
         }
-        if (int rc = four_passes(rows_p, ld * (size_t)pilot, pw)) return rc;
-        hipLaunchKernelGGL(brackets_kernel, dim3((unsigned)((m * nq + 63) / 64)), dim3(64), 0, st, m, nq, tg, ends, binsA, br);
+        if (fused) {                                                        // the producer writes the pilot rows (contiguous) first
+            if (int rc = fused->pilot(rows_p, const_cast<double*>(data), st)) return cleanup(rc);
+            if (int rc = four_passes(rows_p, ld, pw)) return rc;
+        } else if (int rc = four_passes(rows_p, ld * (size_t)pilot, pw)) return rc;
         // 2. pass A over everything: below / inside counts; the ranks inside their brackets become sub-bins
         const dim3 grid = grid_for(n);
-        Q_TRY(hipMemsetAsync(total, 0, 256, st));                           // total, outside
+        Q_TRY(hipMemsetAsync(total, 0, 256, st));                           // total, outside, any_single
         Q_TRY(hipMemsetAsync(below, 0, o_end - o_bl, st));                  // below, histA
+        hipLaunchKernelGGL(brackets_kernel, dim3((unsigned)((m * nq + 63) / 64)), dim3(64), 0, st, m, nq, tg, ends, binsA, br, any_single);
         hipLaunchKernelGGL(init_columns_kernel, dim3(cblocks), dim3(64), 0, st, col, tg, m, nq, w);
 #define Q_BRHIST_(NC_, NQ_)                                                                                                  \
     Q_LDS((bracket_hist_kernel<NC_, NQ_>));                                                                                  \
-    hipLaunchKernelGGL((bracket_hist_kernel<NC_, NQ_>), grid, blk, ldsA, st, (long long)n, m, ld, cs, data, br, binsA, col, below, histA)
+    hipLaunchKernelGGL((bracket_hist_kernel<NC_, NQ_>), grid, blk, ldsA, st, (long long)n, m, ld, cs, data, br, any_single, binsA, col, below, histA)
 #define Q_BRHIST(NC_) Q_BY_NQ_##NC_(Q_BRHIST_, NC_)
-        Q_BY_NC(Q_BRHIST);
+        unsigned rcap = 0;
+        if (!fused) {
+            Q_BY_NC(Q_BRHIST);
+        } else {
+            // brackets the producer can count against?  (one small read: nothing else has to wait for the host here)
+            hipLaunchKernelGGL(bracket_check_kernel, dim3((unsigned)((m * nq + 63) / 64)), dim3(64), 0, st, m, nq, br, unfit);
+            int h_unfit = 0;
+            Q_TRY(hipMemcpyAsync(&h_unfit, unfit, sizeof(int), hipMemcpyDeviceToHost, st));
+            Q_TRY(hipStreamSynchronize(st));
+            if (h_unfit) {
+                *fused_ok = 0;
+                return cleanup(PEM_OK);
+            }
+            // record room per wave: the brackets hold `expected` values of the array (their ranks in the subsample say so) -- half as
+            // much again, and a few thousand for the waves that get more than their share
+            double expected = 0.0;
+            for (int q = 0; q < nq; ++q) expected += (double)(pw.next[q] - pw.prev[q] + 1) * (double)pilot * (double)m;
+            rcap = (unsigned)(1.5 * expected / (double)fused_waves) + 4096u;
+            if (const char* e = getenv("PEM_QUANTILE_RECORD_CAP")) rcap = (unsigned)atoll(e);      // (tests: force the overflow path)
+            const size_t need = (size_t)fused_waves * rcap;
+            if (rec_cap < need) {
+                if (rec_buf) (void)hipFree(rec_buf);
+                rec_buf = nullptr;
+                rec_cap = 0;
+                Q_TRY(hipMalloc(&rec_buf, need * sizeof(pem::Record)));
+                rec_cap = need;
+            }
+            pem::CountIO cio;
+            cio.br = br;
+            cio.nq = nq;
+            cio.below = reinterpret_cast<unsigned long long*>(below);
+            cio.rec = rec_buf;
+            cio.rec_count = rec_count;
+            cio.cap = rcap;
+            cio.flags = prod_flags;
+            if (int rc = fused->count(cio, st)) return cleanup(rc);
+            static pem::LdsAttrOnce attr;
+            Q_TRY(attr.ensure(reinterpret_cast<const void*>(record_hist_kernel), 150 * 1024));       // (+ its static tables)
+            int cus = 256;
+            Q_TRY(pem::device_cus(&cus));
+            hipLaunchKernelGGL(record_hist_kernel, dim3((unsigned)cus), blk, (size_t)m * nq * binsA * 4, st, rec_buf, rec_count, rcap, fused_waves, br,
+                               m * nq, binsA, histA);
+        }
         hipLaunchKernelGGL(decide_bracket_kernel, dim3((unsigned)(m * nt)), dim3(64), 0, st, nt, col, br, below, histA, binsA, tg, outside);
         hipLaunchKernelGGL(layout_kernel, dim3(1), dim3(64 * MAX_NC), 0, st, m, nt, tg, total);
         Q_TRY(hipGetLastError());
         u64 h_tot[2] = {0, 0};
+        int h_prod[2] = {0, 0};
         Q_TRY(hipMemcpyAsync(h_tot, total, 2 * sizeof(u64), hipMemcpyDeviceToHost, st));
+        if (fused) Q_TRY(hipMemcpyAsync(h_prod, prod_flags, sizeof h_prod, hipMemcpyDeviceToHost, st));
         Q_TRY(hipStreamSynchronize(st));
+        if (fused && ((int)(h_tot[1] & 0xffffffffull) != 0 || h_prod[0] || h_prod[1])) {
+            *fused_ok = 0;                                                  // a rank outside its bracket, record overflow, a non-finite sample
+            return cleanup(PEM_OK);
+        }
         if ((int)(h_tot[1] & 0xffffffffull) == 0) {
             // 3. pass B: the values of those sub-bins, then the lists as in the four-pass form
             Q_TRY(grow_candidates(h_tot[0]));
@@ -1191,7 +1371,13 @@ extern "C" int pem_quantiles_strided_f64_dev(size_t n, int m, const double* data
 #define Q_BRCOMPACT_(NC_, NQ_) \
     hipLaunchKernelGGL((compact_bracket_kernel<NC_, NQ_>), grid, blk, 0, st, (long long)n, m, ld, cs, data, br, tg, cand)
 #define Q_BRCOMPACT(NC_) Q_BY_NQ_##NC_(Q_BRCOMPACT_, NC_)
-            Q_BY_NC(Q_BRCOMPACT);
+            if (!fused) {
+                Q_BY_NC(Q_BRCOMPACT);
+            } else {
+                int cus = 256;
+                Q_TRY(pem::device_cus(&cus));
+                hipLaunchKernelGGL(record_compact_kernel, dim3((unsigned)(cus * 2)), blk, 0, st, rec_buf, rec_count, rcap, fused_waves, br, m * nq, tg, cand);
+            }
             hipLaunchKernelGGL(select_kernel, dim3((unsigned)(m * nt)), blk, 0, st, nt, tg, cand, incomplete);
             Q_TRY(hipGetLastError());
             answered = true;
@@ -1215,6 +1401,7 @@ extern "C" int pem_quantiles_strided_f64_dev(size_t n, int m, const double* data
                          "discarded; path %d)",
                          h_incomplete[1] / nt, h_incomplete[1] % nt, h_incomplete[2], h_incomplete[3], path);
     g_last_path.store(path);
+    if (fused_ok) *fused_ok = 1;
 #undef Q_BRCOMPACT
 #undef Q_BRCOMPACT_
 #undef Q_BRHIST
@@ -1239,6 +1426,16 @@ extern "C" int pem_quantiles_strided_f64_dev(size_t n, int m, const double* data
 #undef Q_LDS
 #undef Q_TRY
     return cleanup(PEM_OK);
+}
+
+extern "C" int pem_quantiles_strided_f64_dev(size_t n, int m, const double* data, size_t ld, size_t cs, int nq, const uint64_t* rank_prev,
+                                             const uint64_t* rank_next, const double* gamma, double* out, pem_stream_t stream) {
+    return quantiles_impl(n, m, data, ld, cs, nq, rank_prev, rank_next, gamma, out, stream, nullptr, nullptr);
+}
+
+int pem::quantiles_fused(size_t n, int m, int nq, const uint64_t* rank_prev, const uint64_t* rank_next, const double* gamma, double* pilot_rows,
+                         pem::FusedProducer& prod, double* out, int* fused_ok, hipStream_t st) {
+    return quantiles_impl(n, m, pilot_rows, (size_t)m, 1, nq, rank_prev, rank_next, gamma, out, static_cast<pem_stream_t>(st), &prod, fused_ok);
 }
 
 extern "C" int pem_quantiles_f64_dev(size_t n, int m, const double* data, size_t ld, int nq, const uint64_t* rank_prev, const uint64_t* rank_next,

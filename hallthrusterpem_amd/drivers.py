@@ -26,21 +26,12 @@ COORDS_STR_ID = '_coords'      # amisc.typing.COORDS_STR_ID as the reference use
 MAX_Q, MAX_Q_WIDE = 6, 3     # include/pem_hip.h PEM_QUANTILE_MAX_Q, PEM_QUANTILE_MAX_Q_WIDE: quantiles per selection (<= 128 / <= 256 columns)
 
 
-def column_percentiles(a, percentiles):
-    """`np.percentile(a, percentiles, axis=0)` (method 'linear') of a CUDA tensor `a` of shape (n, ...), bit for bit, by exact
-    selection on the device (`pem_quantiles_f64_dev`, csrc/pem_quantile.hip) -- the percentiles of gen_data.py:125-174 and
-    monte_carlo.py:363-658 at sizes where a sort-based quantile gives up (torch.quantile: 2^24 values per column).
-    Returns a CUDA tensor of shape (len(percentiles), ...) (or (...) for a scalar percentile); a column that holds a NaN
-    gives NaN, as numpy does."""
-    import ctypes as C
-    import torch
-    from . import _lib
-    scalar = np.ndim(percentiles) == 0
-    # numpy's own index arithmetic (numpy/lib/_function_base_impl.py: percentile -> _quantile, method 'linear')
+def _linear_ranks(n: int, percentiles):
+    """The two order statistics numpy's method 'linear' reads per percentile of n values, and its interpolation weight
+    (numpy/lib/_function_base_impl.py: percentile -> _quantile): (rank_prev, rank_next) uint64, gamma float64."""
     q = np.true_divide(np.atleast_1d(np.asarray(percentiles, dtype=np.float64)), np.float64(100))
     if not np.all((q >= 0) & (q <= 1)):
         raise ValueError('Percentiles must be in the range [0, 100]')
-    n = int(a.shape[0])
     if n == 0:
         raise ValueError('no samples')
     virtual = (n - 1) * q
@@ -51,6 +42,22 @@ def column_percentiles(a, percentiles):
     gamma = virtual - prev                                  # (numpy takes the weight from the clipped index as well)
     rank_prev = np.where(prev < 0, n - 1, prev).astype(np.uint64)
     rank_next = np.where(nxt < 0, n - 1, nxt).astype(np.uint64)
+    return rank_prev, rank_next, gamma
+
+
+def column_percentiles(a, percentiles):
+    """`np.percentile(a, percentiles, axis=0)` (method 'linear') of a CUDA tensor `a` of shape (n, ...), bit for bit, by exact
+    selection on the device (`pem_quantiles_f64_dev`, csrc/pem_quantile.hip) -- the percentiles of gen_data.py:125-174 and
+    monte_carlo.py:363-658 at sizes where a sort-based quantile gives up (torch.quantile: 2^24 values per column).
+    Returns a CUDA tensor of shape (len(percentiles), ...) (or (...) for a scalar percentile); a column that holds a NaN
+    gives NaN, as numpy does."""
+    import ctypes as C
+    import torch
+    from . import _lib
+    scalar = np.ndim(percentiles) == 0
+    n = int(a.shape[0])
+    rank_prev, rank_next, gamma = _linear_ranks(n, percentiles)
+    q = gamma
     a = a.double()
     # a (n, m) view whose columns are contiguous arrays -- e.g. `batch.qoi.T`, the [3][n] reduced-QoI tensor seen as (n, 3) --
     # is read in place (`pem_quantiles_strided_f64_dev`): the three scalar QoIs of a campaign in ONE selection, without a copy
@@ -307,6 +314,81 @@ def campaign_statistics(outputs: dict, iqr_factor: float = 1.5, percentiles=(5.0
         outlier_idx[k] = count > int(0.75 * per_sample)
         bands[k] = qk[2:]
     return nan_idx, outlier_idx, bands
+
+
+FUSED_STATS_MIN_N = 4096      # include/pem_hip.h PEM_MC_STATS_MIN_N
+
+
+def forward_uq_statistics(n: int, seed: int = 0, keep_profile: bool = True, percentiles=(5.0, 50.0, 95.0), iqr_factor: float = 1.5,
+                          priors=None, device=None, keep_inputs: bool = False, fused: bool = True):
+    """One forward-UQ campaign of scripts/pem_v0/monte_carlo.py:63-300 / gen_data.py:218-258 on one GPU, statistics included:
+    `forward_uq(n, seed, method='mc')`, the NaN / IQR masks of `filter_outputs` and the bands of `percentile_bands` -- with the
+    percentiles of the 91-point profile COUNTED WHERE THE PROFILE IS PRODUCED (`pem_coupled_mc_stats_f64_dev`, csrc/pem_qfused.h):
+    the samples of the first 3 % are evaluated and bracket the wanted ranks, one launch evaluates everything and counts every
+    profile value against the brackets on chip, the order statistics come from the 4 % of values inside them.  The profile is
+    not read back for its percentiles (five reads of 7.3 GB per 1e7 samples in round 3; one, for the masks, now) and with
+    `keep_profile=False` it is never written at all.
+
+    Returns the dictionary of `forward_uq` plus 'nan_idx', 'outlier_idx' (per output variable, as `filter_outputs`; the profile's
+    masks only when it is kept) and 'bands' ({name: (len(percentiles), ...)} as `percentile_bands`), every number equal to numpy's
+    on the same samples bit for bit.  'fused': whether the on-chip selection answered (heavy ties or a non-finite profile value
+    make it decline: the percentiles then come from passes over the stored profile -- evaluated again with the profile kept when
+    `keep_profile=False`)."""
+    import ctypes as C
+    import torch
+    from . import _lib, constants
+    design = sampling.Design(priors=priors, seed=seed)
+    batch = CoupledBatch(n, device=device, profile=keep_profile)
+    pct = [25.0, 75.0] + [float(x) for x in percentiles]
+    if len(pct) > MAX_Q:
+        raise ValueError(f'at most {MAX_Q - 2} percentiles besides the quartiles')
+    answered, qj = False, None
+    with torch.cuda.device(batch.device):
+        stream = torch.cuda.current_stream(batch.device)
+        if fused and n >= FUSED_STATS_MIN_N:
+            rp, rn, gm = _linear_ranks(n, pct)
+            qj = torch.empty((len(pct), _lib.NANGLE), dtype=torch.float64, device=batch.device)
+            pilot = None if keep_profile else torch.empty(((n + 31) // 32, _lib.NANGLE), dtype=torch.float64, device=batch.device)
+            ok = C.c_int(0)
+            ptr = lambda arr: C.c_void_p(arr.ctypes.data)                                       # noqa: E731
+            outs = batch._out_ptrs
+            _lib.check(_lib.load().pem_coupled_mc_stats_f64_dev(
+                n, 0, design.seed, design.stream, ptr(design.kind), ptr(design.a), ptr(design.b), constants.TORR_2_PA, batch.radius,
+                C.c_void_p(batch.inputs.data_ptr()) if keep_inputs else None, batch.inputs.stride(0),
+                outs[0], outs[1], outs[2], outs[3], None if pilot is None else C.c_void_p(pilot.data_ptr()), outs[4], outs[5], outs[6],
+                len(pct), ptr(rp), ptr(rn), ptr(gm), C.c_void_p(qj.data_ptr()), C.byref(ok), C.c_void_p(stream.cuda_stream)))
+            answered = bool(ok.value)
+            del pilot
+        else:
+            batch.run_mc(design, first_index=0, write_inputs=keep_inputs)
+    out = {k: batch.qoi[i] for i, k in enumerate(QOI_NAMES)}
+    out.update(I_B0=batch.I_B0, T=batch.T, invalid=batch.invalid.bool())
+    if keep_inputs:
+        out['x'] = batch.inputs
+    if keep_profile:
+        out['j_ion'] = batch.j_ion
+    if not answered:                         # the passes over the stored profile
+        if keep_profile:
+            qj = column_percentiles(batch.j_ion, pct)
+        else:
+            full = CoupledBatch(n, device=device, profile=True, thruster_qoi=False)
+            full.run_mc(design, first_index=0)
+            qj = column_percentiles(full.j_ion, pct)
+            del full
+    qs = column_percentiles(batch.qoi.T, pct)                      # the three scalar QoIs in one selection
+    q = {k: qs[:, i] for i, k in enumerate(QOI_NAMES)}
+    q['j_ion'] = qj
+    nan_idx, outlier_idx, bands = {}, {}, {}
+    for k in list(QOI_NAMES) + (['j_ion'] if keep_profile else []):
+        a, qk = out[k], q[k]
+        per_sample = int(np.prod(a.shape[1:])) if a.dim() > 1 else 1
+        iqr = qk[1] - qk[0]
+        nan_idx[k], count = _row_masks(a, qk[0] - iqr_factor * iqr, qk[1] + iqr_factor * iqr, per_sample)
+        outlier_idx[k] = count > int(0.75 * per_sample)
+    for k in q:
+        bands[k] = q[k][2:]
+    out.update(nan_idx=nan_idx, outlier_idx=outlier_idx, bands=bands, fused=answered)
+    return out
 
 
 def generate_data(system, description: str, num_samples: int = 500, executor=None, verbose: bool = False,

@@ -305,6 +305,25 @@ int pem_quantiles_strided_f64_dev(size_t n, int m, const double* data, size_t ld
                                   const uint64_t* rank_next, const double* gamma, double* out, pem_stream_t stream);
 int pem_quantiles_last_path(void);
 
+/* Fused Monte-Carlo evaluation + percentiles of the profile, counted where the profile is produced (round 4; csrc/pem_qfused.h):
+ * `sample_inputs` + `predict` of scripts/gen_data.py:238-239 followed by the `np.percentile(j_ion, ..., axis=0)` of
+ * gen_data.py:163-168 and scripts/pem_v0/monte_carlo.py:363-658, without reading the profile back.  The arguments of
+ * pem_coupled_mc_f64_dev (plain Monte-Carlo block: swap_dim -1) and of pem_quantiles_f64_dev (HOST arrays rank_prev / rank_next /
+ * gamma of nq <= PEM_QUANTILE_MAX_Q quantiles of the n samples; q_out [nq][91] on the device).  Samples 0 .. ceil(n / 32) - 1 are
+ * evaluated first and bracket the wanted ranks; ONE launch then evaluates all n samples, counts every profile value against the
+ * brackets in LDS and writes the values inside them (4 %) out as records, from which the order statistics are selected.
+ * j_ion NULL: the profile is never stored (pilot_rows: room for ceil(n / 32) x 91 doubles then holds the pilot's rows; ignored
+ * when j_ion is given).  *fused_ok = 1: q_out equals np.percentile of the profile bit for bit.  *fused_ok = 0: the selection
+ * declined -- brackets of one key or overlapping (heavy ties), a rank outside its bracket, a non-finite profile value, record
+ * overflow -- q_out is not written; all other outputs are complete either way, and the caller takes pem_quantiles_f64_dev over
+ * the stored profile.  n >= PEM_MC_STATS_MIN_N.  Synchronises the stream.                                                          */
+#define PEM_MC_STATS_MIN_N 4096
+int pem_coupled_mc_stats_f64_dev(size_t n, uint64_t first_index, uint64_t seed, uint32_t stream_id, const int32_t* kind, const double* a,
+                                 const double* b, double torr2pa, double radius, double* x_out, size_t ld, double* V_cc, double* I_B0,
+                                 double* T, double* j_ion, double* pilot_rows, double* div_angle, double* T_c, uint8_t* invalid, int nq,
+                                 const uint64_t* rank_prev, const uint64_t* rank_next, const double* gamma, double* q_out, int* fused_ok,
+                                 pem_stream_t stream);
+
 /* The per-sample masks of `_filter_outputs` (scripts/gen_data.py:150-168) for one output variable in one pass over it
  * (csrc/pem_masks.hip): data [n][ld] row-major, entries 0..m-1 of a sample; lo / hi: m per-entry bounds each (DEVICE arrays:
  * p25 - f iqr and p75 + f iqr, computed by the caller from pem_quantiles_f64_dev's result as the reference does);

@@ -300,6 +300,61 @@ def test_campaign_statistics_equal_the_two_separate_calls():
         assert torch.equal(nan_c[k], nan_a[k]) and torch.equal(outl_c[k], outl_a[k]) and torch.equal(bands_c[k], bands_a[k])
 
 
+@pytest.mark.parametrize('n,keep', [(300_000, True), (300_000, False), (70_001, True), (4_096, False)])
+def test_fused_campaign_statistics_equal_numpy(n, keep):
+    """drivers.forward_uq_statistics (pem_coupled_mc_stats_f64_dev): the percentiles of the profile counted inside the evaluation
+    kernel -- brackets from the first 3 % of the samples, one evaluate-and-count launch, selection from the records -- against
+    np.percentile of the profile the plain campaign writes, bit for bit; the other outputs, masks and bands against the separate
+    calls; with and without a stored profile; a ragged last tile."""
+    import torch
+    from hallthrusterpem_amd import drivers
+    ref = drivers.forward_uq(n, seed=21, keep_profile=True, keep_inputs=False)
+    got = drivers.forward_uq_statistics(n, seed=21, keep_profile=keep)
+    assert got['fused'] is (n >= 50_000)                     # (4096 samples: the brackets of 128 pilot rows overlap -- declined, still right)
+    for k in ('V_cc', 'div_angle', 'T_c', 'I_B0', 'T', 'invalid'):
+        if got['fused'] or keep:
+            assert torch.equal(got[k], ref[k]), k            # the counting launch integrates the profile as the profile mode does
+        else:                                                # (declined without a profile: the reduced-QoI launch, equal within its tolerance)
+            assert torch.allclose(got[k].double(), ref[k].double(), rtol=1e-10, atol=0.0), k
+    assert ('j_ion' in got) == keep
+    if keep:
+        assert torch.equal(got['j_ion'], ref['j_ion'])
+    want = np.percentile(ref['j_ion'].cpu().numpy(), [5.0, 50.0, 95.0], axis=0)
+    assert np.array_equal(got['bands']['j_ion'].cpu().numpy(), want)
+    own = {k: got[k] for k in ('V_cc', 'div_angle', 'T_c')}
+    bands = drivers.percentile_bands(own)
+    for k in own:
+        assert torch.equal(got['bands'][k], bands[k]), k
+    nan_a, outl_a = drivers.filter_outputs(dict(own, j_ion=ref['j_ion']))
+    for k in got['nan_idx']:
+        assert torch.equal(got['nan_idx'][k], nan_a[k]) and torch.equal(got['outlier_idx'][k], outl_a[k]), k
+    assert set(got['nan_idx']) == ({'V_cc', 'div_angle', 'T_c', 'j_ion'} if keep else {'V_cc', 'div_angle', 'T_c'})
+
+
+def test_fused_campaign_statistics_decline_and_fall_back(monkeypatch):
+    """What makes the on-chip selection decline leaves the results right: priors under which many samples are invalid (their
+    profile is the constant 1e-20: brackets of one key), record regions that are too small, other percentile sets."""
+    import torch
+    from hallthrusterpem_amd import drivers, sampling
+    n = 200_000
+    pri = dict(sampling.PEM_V0_PRIORS)
+    pri['c3'] = sampling.Prior(sampling.UNIFORM, -0.6, 1.1, 'test')          # alpha1 <= 0 for a third of the samples (plume.py:105)
+    got = drivers.forward_uq_statistics(n, seed=5, keep_profile=True, priors=pri, percentiles=(5.0, 50.0, 95.0))
+    assert got['fused'] is False and float(got['invalid'].float().mean()) > 0.2
+    j = got['j_ion'].cpu().numpy()
+    assert np.array_equal(got['bands']['j_ion'].cpu().numpy(), np.percentile(j, [5.0, 50.0, 95.0], axis=0))
+    nof = drivers.forward_uq_statistics(n, seed=5, keep_profile=False, priors=pri)
+    assert nof['fused'] is False and torch.equal(nof['bands']['j_ion'], got['bands']['j_ion'])
+    monkeypatch.setenv('PEM_QUANTILE_RECORD_CAP', '8')                          # every wave overflows its records
+    small = drivers.forward_uq_statistics(n, seed=6, keep_profile=True)
+    monkeypatch.delenv('PEM_QUANTILE_RECORD_CAP')
+    assert small['fused'] is False
+    ok = drivers.forward_uq_statistics(n, seed=6, keep_profile=True, percentiles=(0.0, 1.0, 99.0, 100.0))
+    assert ok['fused'] is True and torch.equal(ok['j_ion'], small['j_ion'])
+    assert np.array_equal(ok['bands']['j_ion'].cpu().numpy(), np.percentile(ok['j_ion'].cpu().numpy(), [0.0, 1.0, 99.0, 100.0], axis=0))
+    assert np.array_equal(small['bands']['j_ion'].cpu().numpy(), np.percentile(ok['j_ion'].cpu().numpy(), [5.0, 50.0, 95.0], axis=0))
+
+
 def test_percentile_bands_of_a_forward_uq_campaign():
     from hallthrusterpem_amd import drivers
     out = drivers.forward_uq(300_000, seed=4, keep_profile=True)

@@ -42,3 +42,8 @@ print(f'  whole campaign                          {total * 1e3:8.2f} ms   {n / t
 print(f'  masks + bands from ONE selection of five quantiles per variable (campaign_statistics) {t_stats * 1e3:8.2f} ms'
       f'   [five quantiles of j_ion {t_qj * 1e3:.2f} ms, of the three scalars in one call {t_qs * 1e3:.2f} ms]')
 print(f'  whole campaign, that way                {(t_model + t_stats) * 1e3:8.2f} ms   {n / (t_model + t_stats) / 1e9:6.2f} G evals/s')
+t_fused = wall(lambda: drivers.forward_uq_statistics(n, seed=2, keep_profile=True))
+t_fused_np = wall(lambda: drivers.forward_uq_statistics(n, seed=2, keep_profile=False))
+r = drivers.forward_uq_statistics(n, seed=2, keep_profile=True)
+print(f'  forward_uq_statistics: sample + evaluate + count on chip, masks, bands (fused={r["fused"]})  {t_fused * 1e3:8.2f} ms   {n / t_fused / 1e9:6.2f} G evals/s')
+print(f'  the same without a stored profile (scalar masks, all bands)                               {t_fused_np * 1e3:8.2f} ms   {n / t_fused_np / 1e9:6.2f} G evals/s')
