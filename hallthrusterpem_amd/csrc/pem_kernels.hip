@@ -314,22 +314,43 @@ struct QCount {
     unsigned below_off;          // LDS [NQ][91]
     pem::Record* rec;            // this wave's region
     unsigned cap, cnt;           // its size; records produced so far (wave-uniform)
+    unsigned pm_off;             // LDS [91] uint4: the premask's thresholds
 };
 struct NoCount {};
 
-template <int NQ, int S, bool FULL>
+// PM: the outlier test of gen_data.py:163-168 rides along (the "premask").  A sample is an outlier of the profile when more than
+// int(0.75 * 91) of its values lie outside [p25 - f iqr, p75 + f iqr] per angle -- bounds that are not known until the selection
+// is done.  But p25 and p75 are known to lie in their brackets, so the bounds lie in intervals [lo_min, lo_max], [hi_min, hi_max]
+// (rounded as numpy rounds them; every operation is monotone), and a value is either OUTSIDE FOR CERTAIN (below lo_min or above
+// hi_max), INSIDE FOR CERTAIN, or uncertain (in one of the two intervals: about one value in a hundred).  Per sample the two
+// counts leave as bytes; the caller settles the few samples whose verdict the uncertain values could change.  Four comparisons of
+// high words per value, kept as wave masks; a row's counts are population counts of those masks.
+template <int NQ, int S, bool FULL, bool PM>
 __device__ __attribute__((noinline)) unsigned count_round(unsigned tab_off, unsigned below_off, unsigned tile_off, pem::Record* rec,
-                                                          unsigned cap, unsigned cnt, int lane, int rows) {
+                                                          unsigned cap, unsigned cnt, int lane, int rows, unsigned pm_off,
+                                                          uint8_t* row_certain, uint8_t* row_uncertain) {
+#if defined(PEM_COUNT_EXP) && PEM_COUNT_EXP == 1
+    return cnt;
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const uint2* tab = reinterpret_cast<const uint2*>(smem_raw + tab_off);
     unsigned* below = reinterpret_cast<unsigned*>(smem_raw + below_off);
     const double* tile = reinterpret_cast<const double*>(smem_raw + tile_off);
+    const uint4* pm = reinterpret_cast<const uint4*>(smem_raw + pm_off);   // [91] {certainly below, possibly below, possibly above, certainly above}
     unsigned bits = 0;           // bit 16 slot + s: value s of the slot's angle lies inside a bracket
+    unsigned row_c = 0, row_u = 0;   // lane s: values of row s outside for certain / uncertain
     static_assert(S <= 16, "one bit per sample and slot");
+    // Two slots: angles 0..63, one row per wave instruction (lane = angle), and angles 64..90, TWO rows per instruction in full
+    // tiles (lanes 0..26 and 32..58: 24 instructions' worth of values per round instead of 32).
+    // (Rolled loops on purpose: fully unrolled, the scheduler hoisted every read of the round and the function took 248 registers,
+    // or turned every borrow into a 0 / 1 register.  Comparisons are kept as wave masks -- v_cmp into a scalar pair, s_or, and back
+    // as a lane condition: written with plain bools every one of them was materialised, 37 instructions per value instead of 19.)
 #pragma unroll
     for (int slot = 0; slot < 2; ++slot) {
-        const int col = lane + 64 * slot;
-        const bool on = col < NANG;
+        const int half = (FULL && slot == 1) ? lane >> 5 : 0;      // which of the instruction's two rows this lane looks at
+        const int sub = slot == 1 ? (lane & 31) : lane;
+        const int col = 64 * slot + sub;
+        const bool on = slot == 0 || (sub < NANG - 64 && (FULL || lane < 32));
         const int cc = on ? col : NANG - 1;           // idle lanes of the second slot repeat the last angle and keep nothing
         uint2 tb[NQ];
         unsigned nb[NQ];
@@ -338,15 +359,15 @@ __device__ __attribute__((noinline)) unsigned count_round(unsigned tab_off, unsi
             tb[q] = tab[cc * NQ + q];
             nb[q] = 0;
         }
-        const int* hw = reinterpret_cast<const int*>(tile) + 2 * cc + 1;   // the high words of this angle's values
-        // (a rolled loop on purpose: fully unrolled, the scheduler hoisted every read of the round and the function took 248 registers)
-        // (comparisons kept as wave masks -- v_cmp into a scalar pair, s_or, and back as a lane condition: written with plain
-        // bools the compiler materialised every one of them as 0 / 1 in a register, 37 instructions per value instead of 19)
+        const int* hw = reinterpret_cast<const int*>(tile) + 2 * cc + 1 + half * 2 * NANG;   // the high words of this lane's values
+        uint4 th = make_uint4(0u, 0u, 0u, 0u);
+        if constexpr (PM) th = pm[cc];
+        constexpr unsigned long long PART = (1ull << (NANG - 64)) - 1;
+        const unsigned long long lanes_on = slot == 0 ? ~0ull : (FULL ? (PART | (PART << 32)) : PART);
         unsigned mine = 0;
-        const int nrows = FULL ? S : rows;            // (a compile-time trip count lets the loop be unrolled around the wave-level builtins)
-#pragma unroll 4
-        for (int s = 0; s < nrows; ++s) {
-            const unsigned kh = pem::order_key_high(hw[s * 2 * NANG]);
+        // one value per lane: the brackets' below-counts and "inside any" (then `bit` is noted); the premask's two wave masks
+        auto one = [&](int row, unsigned bit, unsigned long long& certain, unsigned long long& maybe) {
+            const unsigned kh = pem::order_key_high(hw[row * 2 * NANG]);
             unsigned long long in = 0;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
@@ -354,37 +375,107 @@ __device__ __attribute__((noinline)) unsigned count_round(unsigned tab_off, unsi
                 nb[q] += __builtin_sub_overflow(kh, tb[q].x, &t) ? 1u : 0u;
                 in |= __builtin_amdgcn_uicmp(t, tb[q].y, 37 /* ICMP_ULE */);   // (a borrow leaves t above every `words`)
             }
-            mine |= __builtin_amdgcn_inverse_ballot_w64(in) ? (1u << s) : 0u;
+            mine |= __builtin_amdgcn_inverse_ballot_w64(in) ? bit : 0u;
+            if constexpr (PM) {
+                certain = (__builtin_amdgcn_uicmp(kh, th.x, 36 /* ULT */) | __builtin_amdgcn_uicmp(kh, th.w, 34 /* UGT */)) & lanes_on;
+                maybe = (__builtin_amdgcn_uicmp(kh, th.y, 37 /* ULE */) | __builtin_amdgcn_uicmp(kh, th.z, 35 /* UGE */)) & lanes_on & ~certain;
+            }
+        };
+        if constexpr (FULL) {
+            // four rows a turn (explicit groups: the wave-level builtins keep the compiler from unrolling a counted loop with a
+            // remainder).  The premask's counts of the four rows -- scalars, at most 64 + 27 each over the two slots -- are packed
+            // into one word and kept by lane `turn`: two vector instructions per four rows instead of six per row.
+            static_assert(S % 4 == 0, "rows in groups of four");
+            const unsigned bit0 = 1u << (16 * slot + half);
+#pragma unroll 1
+            for (int turn = 0; turn < S / 4; ++turn) {
+                unsigned pc = 0, pu = 0;
+                if (slot == 0) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        unsigned long long certain = 0, maybe = 0;
+                        one(4 * turn + u, bit0 << (4 * turn + u), certain, maybe);
+                        if constexpr (PM) {
+                            pc |= (unsigned)__popcll(certain) << (8 * u);
+                            pu |= (unsigned)__popcll(maybe) << (8 * u);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {              // rows 4 turn + 2 u (lanes 0..31) and 4 turn + 2 u + 1 (lanes 32..63)
+                        unsigned long long certain = 0, maybe = 0;
+                        one(4 * turn + 2 * u, bit0 << (4 * turn + 2 * u), certain, maybe);
+                        if constexpr (PM) {
+                            pc |= ((unsigned)__popc((unsigned)certain) << (16 * u)) | ((unsigned)__popc((unsigned)(certain >> 32)) << (16 * u + 8));
+                            pu |= ((unsigned)__popc((unsigned)maybe) << (16 * u)) | ((unsigned)__popc((unsigned)(maybe >> 32)) << (16 * u + 8));
+                        }
+                    }
+                }
+                if constexpr (PM) {
+                    row_c += lane == turn ? pc : 0u;
+                    row_u += lane == turn ? pu : 0u;
+                }
+            }
+        } else {
+            for (int r = 0; r < rows; ++r) {          // the ragged last tile of a launch: row by row, one byte per lane
+                unsigned long long certain = 0, maybe = 0;
+                one(r, 1u << (16 * slot + r), certain, maybe);
+                if constexpr (PM) {
+                    row_c += lane == r ? (unsigned)__popcll(certain) : 0u;
+                    row_u += lane == r ? (unsigned)__popcll(maybe) : 0u;
+                }
+            }
         }
-        bits |= on ? mine << (16 * slot) : 0u;
+        bits |= on ? mine : 0u;
         if (on) {
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
                 if (nb[q]) atomicAdd(&below[q * NANG + col], nb[q]);
         }
     }
+    if constexpr (PM) {
+        if constexpr (FULL) {                          // lane `turn` holds the bytes of rows 4 turn .. 4 turn + 3
+            if (lane < S / 4) {
+                reinterpret_cast<unsigned*>(row_certain)[lane] = row_c;
+                reinterpret_cast<unsigned*>(row_uncertain)[lane] = row_u;
+            }
+        } else if (lane < rows) {
+            row_certain[lane] = (uint8_t)row_c;
+            row_uncertain[lane] = (uint8_t)row_u;
+        }
+    }
+#if defined(PEM_COUNT_EXP) && PEM_COUNT_EXP == 2
+    bits = 0;
+#endif
+    // The records: {key, angle} (which of the angle's brackets holds the key is found again by the passes over the records: they
+    // see 4 % of the values).  Two per lane and turn -- the reads of the tile, and the stores, of both are in flight together --
+    // appended behind the wave's count by however many lanes have one.
     while (__ballot(bits != 0)) {
-        const bool has = bits != 0;
-        const int b = has ? __builtin_ctz(bits) : 0;
+        const bool has0 = bits != 0;
+        const int b0 = has0 ? __builtin_ctz(bits) : 0;
         bits &= bits - 1;                              // (0 stays 0)
-        const int col = has ? lane + 64 * (b >> 4) : 0;
-        const double x = tile[(b & 15) * NANG + col];
-        const unsigned kh = pem::order_key_high(__double2hiint(x));
-        int cq = 0;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const uint2 e = tab[col * NQ + q];
-            cq = (kh - e.x <= e.y) ? q : cq;
-        }
-        const unsigned long long emit = __ballot(has);
-        const unsigned at = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(emit >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)emit, 0u));
-        if (has && at < cap) {
+        const bool has1 = bits != 0;
+        const int b1 = has1 ? __builtin_ctz(bits) : 0;
+        bits &= bits - 1;
+        const int col0 = (b0 >> 4) ? 64 + (lane & 31) : lane, col1 = (b1 >> 4) ? 64 + (lane & 31) : lane;
+        const double x0 = tile[(b0 & 15) * NANG + (has0 ? col0 : 0)], x1 = tile[(b1 & 15) * NANG + (has1 ? col1 : 0)];
+        const unsigned long long e0 = __ballot(has0), e1 = __ballot(has1);
+        const unsigned at0 = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(e0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)e0, 0u));
+        const unsigned n0 = (unsigned)__popcll(e0);
+        const unsigned at1 = cnt + n0 + __builtin_amdgcn_mbcnt_hi((unsigned)(e1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)e1, 0u));
+        if (has0 && at0 < cap) {
             f64x2 r;
-            r.x = __longlong_as_double((long long)pem::order_key(x));
-            r.y = __longlong_as_double((long long)(col * NQ + cq));
-            *reinterpret_cast<f64x2*>(rec + at) = r;
+            r.x = __longlong_as_double((long long)pem::order_key(x0));
+            r.y = __longlong_as_double((long long)col0);
+            *reinterpret_cast<f64x2*>(rec + at0) = r;
         }
-        cnt += (unsigned)__popcll(emit);
+        if (has1 && at1 < cap) {
+            f64x2 r;
+            r.x = __longlong_as_double((long long)pem::order_key(x1));
+            r.y = __longlong_as_double((long long)col1);
+            *reinterpret_cast<f64x2*>(rec + at1) = r;
+        }
+        cnt += n0 + (unsigned)__popcll(e1);
     }
     return cnt;
 }
@@ -392,7 +483,7 @@ __device__ __attribute__((noinline)) unsigned count_round(unsigned tab_off, unsi
 // One 64-sample tile.  FULL = every sample of the tile exists (the steady state of the persistent loop:
 // no bounds checks and a fixed number of stores, so the compiler can count them); FULL = false is the
 // ragged last tile of a batch.
-template <int L, bool COUPLED, int JMODE, bool FULL, int NQ = 0, class QC = NoCount>
+template <int L, bool COUPLED, int JMODE, bool FULL, int NQ = 0, bool PM = false, class QC = NoCount>
 __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO& cio, const WaveLds& m,
                                              const SampleIn<COUPLED>& in, long long t, int lane, double rad,
                                              double inv_r2, double inv_2pi_r2, QC& qc) {
@@ -474,7 +565,11 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
         // ------------------------------ ROUNDS: L lanes per sample ------------------------------
         // (the counting modes keep the rounds rolled: unrolled four times with count_round inside, the kernel took 340 registers
         // and one wave per SIMD)
+#if defined(PEM_COUNT_EXP) && PEM_COUNT_EXP == 3
+        constexpr int ROUND_UNROLL = L;
+#else
         constexpr int ROUND_UNROLL = NQ > 0 ? 1 : L;
+#endif
 #pragma unroll ROUND_UNROLL
         for (int round = 0; round < L; ++round) {
             const int smp = round * S + s;
@@ -597,8 +692,9 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
                 }
                 if constexpr (JMODE == 5) {             // counted, never stored
                     const long long left = io.n - first;
-                    qc.cnt = count_round<NQ, S, FULL>(qc.tab_off, qc.below_off, m.tile_off, qc.rec, qc.cap, qc.cnt, lane,
-                                                      FULL ? S : (int)(left < S ? (left < 0 ? 0 : left) : S));
+                    qc.cnt = count_round<NQ, S, FULL, PM>(qc.tab_off, qc.below_off, m.tile_off, qc.rec, qc.cap, qc.cnt, lane,
+                                                          FULL ? S : (int)(left < S ? (left < 0 ? 0 : left) : S), qc.pm_off,
+                                                          PM ? io.q.row_certain + first : nullptr, PM ? io.q.row_uncertain + first : nullptr);
                     wave_lds_sync();
                     continue;
                 }
@@ -627,8 +723,9 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
                 }
                 if constexpr (JMODE == 4) {             // the stores are on their way (their LDS reads are done): count the tile
                     const long long left = io.n - first;
-                    qc.cnt = count_round<NQ, S, FULL>(qc.tab_off, qc.below_off, m.tile_off, qc.rec, qc.cap, qc.cnt, lane,
-                                                      FULL ? S : (int)(left < S ? (left < 0 ? 0 : left) : S));
+                    qc.cnt = count_round<NQ, S, FULL, PM>(qc.tab_off, qc.below_off, m.tile_off, qc.rec, qc.cap, qc.cnt, lane,
+                                                          FULL ? S : (int)(left < S ? (left < 0 ? 0 : left) : S), qc.pm_off,
+                                                          PM ? io.q.row_certain + first : nullptr, PM ? io.q.row_uncertain + first : nullptr);
                 }
                 wave_lds_sync();
             }
@@ -685,11 +782,11 @@ struct NoDesign {};
 template <bool MC>
 using DesignArg = typename std::conditional<MC, McDesign, NoDesign>::type;
 
-// bytes of LDS the counting modes add per workgroup: brackets' {loh, words} [91][NQ] | below counters [NQ][91]
-template <int NQ>
-constexpr int count_lds_bytes() { return NANG * NQ * 8 + NQ * NANG * 4; }
+// bytes of LDS the counting modes add per workgroup: brackets' {loh, words} [91][NQ] | below counters [NQ][91] | premask thresholds [91] x 16
+template <int NQ, bool PM>
+constexpr int count_lds_bytes() { return NANG * NQ * 8 + NQ * NANG * 4 + (PM ? NANG * 16 + 8 : 0); }
 
-template <int L, bool COUPLED, int JMODE, bool MC = false, int NQ = 0>
+template <int L, bool COUPLED, int JMODE, bool MC = false, int NQ = 0, bool PM = false>
 __global__ __launch_bounds__(WAVE * WPB) __attribute__((amdgpu_waves_per_eu(min_waves_per_simd<JMODE, MC>())))
 void plume_r1_kernel(PlumeIO io, CoupledIO cio, long long ntiles, DesignArg<MC> mc) {
     static_assert(!MC || COUPLED, "the fused Monte-Carlo mode generates the coupled inputs");
@@ -756,6 +853,13 @@ void plume_r1_kernel(PlumeIO io, CoupledIO cio, long long ntiles, DesignArg<MC> 
         qc.rec = io.q.rec + (size_t)gw * io.q.cap;
         qc.cap = io.q.cap;
         qc.cnt = 0;
+        qc.pm_off = 0;
+        if constexpr (PM) {
+            // (16-byte aligned: the tables before it are a whole number of 8-byte words)
+            uint4* pmt = reinterpret_cast<uint4*>((reinterpret_cast<uintptr_t>(qbelow + NQ * NANG) + 15) & ~uintptr_t(15));
+            for (int i = tid; i < NANG; i += WAVE * WPB) pmt[i] = io.q.premask[i];
+            qc.pm_off = (unsigned)(reinterpret_cast<unsigned char*>(pmt) - smem_raw);
+        }
     }
     for (int i = tid; i < NSIMP; i += WAVE * WPB)
         tab_simpson[i] = i < NANG ? make_double2(PEM_SIMPSON_CDEN[i], PEM_SIMPSON_CNUM[i]) : make_double2(0.0, 0.0);
@@ -784,14 +888,14 @@ void plume_r1_kernel(PlumeIO io, CoupledIO cio, long long ntiles, DesignArg<MC> 
     if constexpr (MC) {
         for (; t < nfull; t += nwaves) {
             const SampleIn<COUPLED> in = generate_sample(mc, design, t * WAVE + lane);
-            process_tile<L, COUPLED, JMODE, true, NQ>(io, cio, m, in, t, lane, rad, inv_r2, inv_2pi_r2, qc);
+            process_tile<L, COUPLED, JMODE, true, NQ, PM>(io, cio, m, in, t, lane, rad, inv_r2, inv_2pi_r2, qc);
         }
         if (nfull < ntiles && (nfull % nwaves) == me) {
             const long long g = nfull * WAVE + lane;
             McDesign quiet = mc;
             if (g >= io.n) quiet.x_out = nullptr;       // dead lanes recompute the last sample and store nothing
             const SampleIn<COUPLED> in = generate_sample(quiet, design, g < io.n ? g : io.n - 1);
-            process_tile<L, COUPLED, JMODE, false, NQ>(io, cio, m, in, nfull, lane, rad, inv_r2, inv_2pi_r2, qc);
+            process_tile<L, COUPLED, JMODE, false, NQ, PM>(io, cio, m, in, nfull, lane, rad, inv_r2, inv_2pi_r2, qc);
         }
     } else {
         if (t < nfull) {
@@ -799,14 +903,14 @@ void plume_r1_kernel(PlumeIO io, CoupledIO cio, long long ntiles, DesignArg<MC> 
             for (; t < nfull; t += nwaves) {
                 const SampleIn<COUPLED> in = nxt;
                 if (t + nwaves < nfull) nxt = load_sample<COUPLED>(io, cio, (t + nwaves) * WAVE + lane);
-                process_tile<L, COUPLED, JMODE, true, NQ>(io, cio, m, in, t, lane, rad, inv_r2, inv_2pi_r2, qc);
+                process_tile<L, COUPLED, JMODE, true, NQ, PM>(io, cio, m, in, t, lane, rad, inv_r2, inv_2pi_r2, qc);
             }
         }
         // the ragged last tile (n % 64 samples) goes to the wave that would have been next in line for it
         if (nfull < ntiles && (nfull % nwaves) == me) {
             const long long g = nfull * WAVE + lane;
             const SampleIn<COUPLED> in = load_sample<COUPLED>(io, cio, g < io.n ? g : io.n - 1);
-            process_tile<L, COUPLED, JMODE, false, NQ>(io, cio, m, in, nfull, lane, rad, inv_r2, inv_2pi_r2, qc);
+            process_tile<L, COUPLED, JMODE, false, NQ, PM>(io, cio, m, in, nfull, lane, rad, inv_r2, inv_2pi_r2, qc);
         }
     }
     if constexpr (NQ > 0) {
@@ -1665,10 +1769,10 @@ int fast_grid(long long per_cu, long long ntiles, bool memory_bound, unsigned* g
     return PEM_OK;
 }
 
-template <int L, int JMODE, bool MC, int NQ = 0>
+template <int L, int JMODE, bool MC, int NQ = 0, bool PM = false>
 size_t r1_lds_bytes(const PlumeIO& io) {
     size_t lds = (size_t)fast_lds_doubles<L, JMODE>() * 8;
-    if (NQ > 0) lds += (size_t)count_lds_bytes<(NQ > 0 ? NQ : 1)>();
+    if (NQ > 0) lds += (size_t)count_lds_bytes<(NQ > 0 ? NQ : 1), PM>();
     if (JMODE == 3) lds += (size_t)io.n_cond * (io.n_ang | 1) * 32;
     if (JMODE == 0) lds += (size_t)QPOLY_DOUBLES * 8;
     if (MC) lds += (size_t)MC_LDS_DOUBLES * 8;
@@ -1680,9 +1784,9 @@ size_t r1_lds_bytes(const PlumeIO& io) {
 // waits for a slot turns the tile split into a two-pass schedule -- and capped at two waves per SIMD, which measured
 // best for the HBM-bound modes, three for the profile-less ones: the fused Monte-Carlo kernel uses a third wave to
 // hide Philox's quarter-rate multiplies whenever its register count allows one (<= 168).
-template <int L, bool COUPLED, int JMODE, bool MC, int NQ = 0>
+template <int L, bool COUPLED, int JMODE, bool MC, int NQ = 0, bool PM = false>
 int r1_per_cu(size_t lds, long long* per_cu) {
-    auto kern = plume_r1_kernel<L, COUPLED, JMODE, MC, NQ>;
+    auto kern = plume_r1_kernel<L, COUPLED, JMODE, MC, NQ, PM>;
     // the register count belongs to the code object (one architecture): once per process
     static std::once_flag once;
     static int by_regs = 0;
@@ -1707,18 +1811,18 @@ int r1_per_cu(size_t lds, long long* per_cu) {
 }
 
 // `grid_only`: report the grid the launch would use (the counting modes size their record buffer by it) and launch nothing
-template <int L, bool COUPLED, int JMODE, bool MC = false, int NQ = 0>
+template <int L, bool COUPLED, int JMODE, bool MC = false, int NQ = 0, bool PM = false>
 int launch_r1(const PlumeIO& io, const CoupledIO& cio, hipStream_t st, const McDesign& mc = McDesign{}, unsigned* grid_only = nullptr) {
-    const size_t lds = r1_lds_bytes<L, JMODE, MC, NQ>(io);
+    const size_t lds = r1_lds_bytes<L, JMODE, MC, NQ, PM>(io);
     const long long ntiles = (io.n + WAVE - 1) / WAVE;
     unsigned grid = 0;
-    auto kern = plume_r1_kernel<L, COUPLED, JMODE, MC, NQ>;
+    auto kern = plume_r1_kernel<L, COUPLED, JMODE, MC, NQ, PM>;
     if (lds > 64 * 1024) {
         static pem::LdsAttrOnce attr;
         HIP_TRY(attr.ensure(reinterpret_cast<const void*>(kern)));
     }
     long long per_cu = 0;
-    if (int rc = r1_per_cu<L, COUPLED, JMODE, MC, NQ>(lds, &per_cu)) return rc;
+    if (int rc = r1_per_cu<L, COUPLED, JMODE, MC, NQ, PM>(lds, &per_cu)) return rc;
     // (the counting modes: a persistent grid of resident waves, each with its own region of the record buffer)
     if (int rc = fast_grid(per_cu, ntiles, JMODE == 1 || JMODE == 2, &grid)) return rc;
     if (grid_only) {
@@ -2193,6 +2297,8 @@ int mc_design_of(const pem::McLaunch& a, McDesign* mc) {
 // the counting launch for nq quantiles: instantiated for 3, 5 and 6 brackets per angle (fewer are padded with empty ones)
 template <int JMODE>
 int launch_count(const PlumeIO& io, const CoupledIO& cio, const McDesign& mc, int nq, hipStream_t st, unsigned* grid_only) {
+    // (the premask rides with up to five brackets: six leave no LDS for its thresholds beside two workgroups per CU)
+    if (io.q.premask && nq <= 5) return launch_r1<4, true, JMODE, true, 5, true>(io, cio, st, mc, grid_only);
     if (nq <= 3) return launch_r1<4, true, JMODE, true, 3>(io, cio, st, mc, grid_only);
     if (nq <= 5) return launch_r1<4, true, JMODE, true, 5>(io, cio, st, mc, grid_only);
     return launch_r1<4, true, JMODE, true, 6>(io, cio, st, mc, grid_only);
@@ -2264,6 +2370,7 @@ int pem_coupled_mc_stats_f64_dev(size_t n, uint64_t first_index, uint64_t seed, 
                                  const double* b, double torr2pa, double radius, double* x_out, size_t ld, double* V_cc, double* I_B0,
                                  double* T, double* j_ion, double* pilot_rows, double* div_angle, double* T_c, uint8_t* invalid, int nq,
                                  const uint64_t* rank_prev, const uint64_t* rank_next, const double* gamma, double* q_out, int* fused_ok,
+                                 int q25, int q75, double iqr_factor, uint8_t* row_certain, uint8_t* row_uncertain, int* premask_ok,
                                  pem_stream_t stream) {
     if (!kind || !a || !b || !V_cc || !div_angle || !T_c || !rank_prev || !rank_next || !gamma || !q_out || !fused_ok)
         return fail(PEM_ERR_INVALID_ARG, "pem_coupled_mc_stats: NULL array");
@@ -2296,11 +2403,20 @@ int pem_coupled_mc_stats_f64_dev(size_t n, uint64_t first_index, uint64_t seed, 
     prod.a.T_c = T_c;
     prod.a.invalid = invalid;
     prod.store_profile = j_ion != nullptr;
+    if (row_certain && row_uncertain && premask_ok) {
+        prod.pm_q25 = q25;
+        prod.pm_q75 = q75;
+        prod.pm_factor = iqr_factor;
+        prod.pm_certain = row_certain;
+        prod.pm_uncertain = row_uncertain;
+    }
+    if (premask_ok) *premask_ok = 0;
     *fused_ok = 0;
     // with a profile array the pilot rows are its own first rows (the counting launch writes the same values there again)
     if (int rc = pem::quantiles_fused(n, NANG, nq, rank_prev, rank_next, gamma, j_ion ? j_ion : pilot_rows, prod, q_out, fused_ok,
                                       static_cast<hipStream_t>(stream)))
         return rc;
+    if (premask_ok) *premask_ok = (*fused_ok && prod.pm_done) ? 1 : 0;
     if (!*fused_ok) {
         // declined -- possibly before the counting launch, with nothing but the pilot's samples evaluated: the plain launch makes
         // every output complete (a rare path: 1.5 ms per 1e7 samples where the counting launch had already run)

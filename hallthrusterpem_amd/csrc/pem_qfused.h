@@ -25,7 +25,7 @@ struct Bracket {         // per (column, quantile): the keys lo .. hi, binned on
 
 struct Record {          // a profile value inside a bracket
     unsigned long long key;     // its order-preserving image (pem_quantile.hip key_of)
-    unsigned long long cq;      // column * nq + quantile
+    unsigned long long col;     // its column (which of the column's brackets holds the key: their high words say)
 };
 
 // order-preserving image of a double (negative values reversed, sign bit flipped), and its high word from the value's high word alone
@@ -46,6 +46,11 @@ struct CountIO {
     unsigned* rec_count = nullptr;        // [waves]: records the wave produced (more than cap: it ran out of room, flags[0] is set)
     unsigned cap = 0;
     int* flags = nullptr;                 // [0] a wave's region overflowed, [1] a sample with a non-finite profile was met
+    // the premask (optional, nq <= 5): per column the high words {certainly below, possibly below, possibly above, certainly above} of the
+    // outlier bounds' intervals; per sample the number of its values outside the bounds for certain / uncertain
+    const uint4* premask = nullptr;
+    uint8_t* row_certain = nullptr;
+    uint8_t* row_uncertain = nullptr;
 };
 
 // one fused Monte-Carlo launch (the arguments of pem_coupled_mc_f64_dev)
@@ -70,6 +75,12 @@ __attribute__((visibility("hidden"))) int launch_coupled_mc_count(const McLaunch
 // csrc/pem_quantile.hip: the selection driven by a producer of counts and records instead of by passes over an array
 struct FusedProducer {
     virtual ~FusedProducer() {}
+    // the premask (see CountIO): which two of the quantiles are the quartiles, the IQR factor, where the per-sample counts go;
+    // pm_done says whether the counting launch produced them (not with unfit bounds: zero, non-finite, a negative factor)
+    int pm_q25 = -1, pm_q75 = -1;
+    double pm_factor = 0.0;
+    uint8_t *pm_certain = nullptr, *pm_uncertain = nullptr;
+    int pm_done = 0;
     virtual int pilot(size_t rows, double* dst, hipStream_t st) = 0;                 // write the first `rows` rows of the [n][m] array to dst
     virtual int waves(int nq, unsigned* waves) = 0;                                   // waves of the counting launch
     virtual int count(const CountIO& io, hipStream_t st) = 0;                         // produce the whole array, counting

@@ -909,23 +909,61 @@ __global__ void bracket_check_kernel(int m, int nq, const Bracket* __restrict__ 
     if (bad) atomicExch(unfit, 1);
 }
 
+// The premask's thresholds (csrc/pem_kernels.hip count_round): p25 and p75 lie in their brackets [A, B] and [C, D], so numpy's
+// lo = p25 - f (p75 - p25) and hi = p75 + f (p75 - p25) (gen_data.py:163-168; every operation rounded on its own, every one of
+// them monotone in p25 and p75 for f >= 0) lie in [lo_min, lo_max] and [hi_min, hi_max].  Per column the high words of the
+// four ends' keys; `bad` when an end is zero (the key order splits -0 from +0, numpy's comparison does not), not finite, or f < 0.
+__global__ void premask_bounds_kernel(int m, int nq, const Bracket* __restrict__ br, int q25, int q75, double f, uint4* __restrict__ thr,
+                                      int* __restrict__ bad) {
+#pragma clang fp contract(off)
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= m) return;
+    const double A = value_of(br[c * nq + q25].lo), B = value_of(br[c * nq + q25].hi);
+    const double C = value_of(br[c * nq + q75].lo), D = value_of(br[c * nq + q75].hi);
+    const double iqr_max = D - A, iqr_min = C - B;
+    const double lo_min = A - f * iqr_max, lo_max = B - f * iqr_min, hi_min = C + f * iqr_min, hi_max = D + f * iqr_max;
+    const double v[4] = {lo_min, lo_max, hi_min, hi_max};
+    bool ok = f >= 0.0;
+    for (int i = 0; i < 4; ++i) ok = ok && __builtin_isfinite(v[i]) && v[i] != 0.0;
+    if (!ok) atomicExch(bad, 1);
+    thr[c] = make_uint4(key_high(lo_min), key_high(lo_max), key_high(hi_min), key_high(hi_max));
+}
+
 constexpr int REC_LISTS_MAX = 64 * 2 * PEM_QUANTILE_MAX_Q;     // (column, quantile) pairs the record kernels keep a table of (m <= 128)
 
+// the list (column * nq + quantile) of a record: the bracket of its column whose high words hold the key's (they do not overlap)
+__device__ __forceinline__ int record_list(const uint4* __restrict__ s_br, int nq, const pem::Record& e, unsigned& t) {
+    const unsigned kh = (unsigned)(e.key >> 32);
+    const int c0 = (int)e.col * nq;
+    int cq = c0;
+    t = kh - s_br[c0].x;
+    for (int q = 1; q < nq; ++q) {
+        const unsigned tq = kh - s_br[c0 + q].x;
+        if (tq <= s_br[c0 + q].y) {
+            cq = c0 + q;
+            t = tq;
+        }
+    }
+    return cq;
+}
+
 __global__ __launch_bounds__(QBLOCK) void record_hist_kernel(const pem::Record* __restrict__ rec, const unsigned* __restrict__ rec_count, unsigned cap,
-                                                              unsigned waves, const Bracket* __restrict__ br, int lists, int bins,
+                                                              unsigned waves, const Bracket* __restrict__ br, int lists, int nq, int bins,
                                                               unsigned* __restrict__ hist) {
     extern __shared__ unsigned lds_hist[];                      // [lists][bins]
-    __shared__ uint2 s_br[REC_LISTS_MAX];                       // {loh, mult}
+    __shared__ uint4 s_br[REC_LISTS_MAX];                       // {loh, words, mult, -}
     for (int i = threadIdx.x; i < lists * bins; i += QBLOCK) lds_hist[i] = 0;
-    for (int i = threadIdx.x; i < lists; i += QBLOCK) s_br[i] = make_uint2(br[i].loh, br[i].mult);
+    for (int i = threadIdx.x; i < lists; i += QBLOCK) s_br[i] = make_uint4(br[i].loh, br[i].words, br[i].mult, 0u);
     __syncthreads();
     for (unsigned w = blockIdx.x; w < waves; w += gridDim.x) {
         const unsigned cnt = rec_count[w] < cap ? rec_count[w] : cap;
         const pem::Record* r = rec + (size_t)w * cap;
         for (unsigned i = threadIdx.x; i < cnt; i += QBLOCK) {
             const pem::Record e = r[i];
-            const uint2 b = s_br[e.cq];
-            atomicAdd(&lds_hist[(int)e.cq * bins + (int)__umulhi((unsigned)(e.key >> 32) - b.x, b.y)], 1u);
+            unsigned t;
+            const int cq = record_list(s_br, nq, e, t);
+            if (t > s_br[cq].y) continue;                       // (not a value of any bracket: a NaN's bits -- the producer has flagged the run)
+            atomicAdd(&lds_hist[cq * bins + (int)__umulhi(t, s_br[cq].z)], 1u);
         }
     }
     __syncthreads();
@@ -936,12 +974,12 @@ __global__ __launch_bounds__(QBLOCK) void record_hist_kernel(const pem::Record* 
 }
 
 __global__ __launch_bounds__(QBLOCK) void record_compact_kernel(const pem::Record* __restrict__ rec, const unsigned* __restrict__ rec_count, unsigned cap,
-                                                                 unsigned waves, const Bracket* __restrict__ br, int lists, Target* __restrict__ tg,
+                                                                 unsigned waves, const Bracket* __restrict__ br, int lists, int nq, Target* __restrict__ tg,
                                                                  u64* __restrict__ cand) {
-    __shared__ uint2 s_br[REC_LISTS_MAX];                       // {loh, mult}
+    __shared__ uint4 s_br[REC_LISTS_MAX];                       // {loh, words, mult, -}
     __shared__ int2 s_bin[REC_LISTS_MAX];                       // the sub-bins the quantile's two targets collect (-1: not a list owner)
     for (int i = threadIdx.x; i < lists; i += QBLOCK) {
-        s_br[i] = make_uint2(br[i].loh, br[i].mult);
+        s_br[i] = make_uint4(br[i].loh, br[i].words, br[i].mult, 0u);
         const Target &T0 = tg[2 * i], &T1 = tg[2 * i + 1];     // targets 2q, 2q + 1 of column c sit at (c nq + q) 2
         s_bin[i] = make_int2((!T0.done && (T0.owner & 1) == 0) ? T0.bin2 : -1, (!T1.done && (T1.owner & 1) == 1) ? T1.bin2 : -1);
     }
@@ -951,12 +989,14 @@ __global__ __launch_bounds__(QBLOCK) void record_compact_kernel(const pem::Recor
         const pem::Record* r = rec + (size_t)w * cap;
         for (unsigned i = threadIdx.x; i < cnt; i += QBLOCK) {
             const pem::Record e = r[i];
-            const uint2 b = s_br[e.cq];
-            const int bin = (int)__umulhi((unsigned)(e.key >> 32) - b.x, b.y);
-            const int2 want = s_bin[e.cq];
+            unsigned t;
+            const int cq = record_list(s_br, nq, e, t);
+            if (t > s_br[cq].y) continue;
+            const int bin = (int)__umulhi(t, s_br[cq].z);
+            const int2 want = s_bin[cq];
             const int hit = want.x == bin ? 0 : (want.y == bin ? 1 : -1);
             if (hit >= 0) {
-                Target& T = tg[2 * e.cq + hit];
+                Target& T = tg[2 * cq + hit];
                 cand[T.offset + atomicAdd(&T.cursor, 1ull)] = e.key;
             }
         }
@@ -1120,7 +1160,8 @@ static int quantiles_impl(size_t n, int m, const double* data, size_t ld, size_t
     if (fused)
         if (int rc = fused->waves(nq, &fused_waves)) return rc;
     const size_t b_rc = sizeof(unsigned) * fused_waves;
-    const size_t o_br = o_tot + 256, o_bl = o_br + up(b_br), o_hA = o_bl + up(b_bl), o_rc = o_hA + up(b_hA), o_end = o_rc + up(b_rc);
+    const size_t o_br = o_tot + 256, o_bl = o_br + up(b_br), o_hA = o_bl + up(b_bl), o_rc = o_hA + up(b_hA), o_pm = o_rc + up(b_rc);
+    const size_t o_end = o_pm + up(sizeof(uint4) * (size_t)m);
     static std::mutex mu;
     static char* ws_buf = nullptr;
     static size_t ws_cap = 0, cand_cap = 0, rec_cap = 0;
@@ -1158,8 +1199,10 @@ static int quantiles_impl(size_t n, int m, const double* data, size_t ld, size_t
     int* incomplete = reinterpret_cast<int*>(total + 2);                   // a list shorter or longer than counted (select_kernel), 4 words
     int* any_single = reinterpret_cast<int*>(total + 8);                   // a bracket of one key exists (brackets_kernel)
     int* unfit = reinterpret_cast<int*>(total + 9);                        // fused form: brackets a producer cannot count against
-    int* prod_flags = reinterpret_cast<int*>(total + 10);                  // fused form: the producer's overflow / non-finite flags (2 ints)
+    int* prod_flags = unfit + 1;                                           // fused form: the producer's overflow / non-finite flags (2 ints)
     unsigned* rec_count = reinterpret_cast<unsigned*>(ws + o_rc);
+    uint4* pm_thr = reinterpret_cast<uint4*>(ws + o_pm);
+    int* pm_bad = unfit + 3;                                               // fused form: premask bounds unfit
     Bracket* br = reinterpret_cast<Bracket*>(ws + o_br);
     u64* below = reinterpret_cast<u64*>(ws + o_bl);
     unsigned* histA = reinterpret_cast<unsigned*>(ws + o_hA);
@@ -1315,9 +1358,17 @@ static int quantiles_impl(size_t n, int m, const double* data, size_t ld, size_t
         } else {
             // brackets the producer can count against?  (one small read: nothing else has to wait for the host here)
             hipLaunchKernelGGL(bracket_check_kernel, dim3((unsigned)((m * nq + 63) / 64)), dim3(64), 0, st, m, nq, br, unfit);
-            int h_unfit = 0;
-            Q_TRY(hipMemcpyAsync(&h_unfit, unfit, sizeof(int), hipMemcpyDeviceToHost, st));
+            const bool want_pm = fused->pm_q25 >= 0 && fused->pm_q25 < nq && fused->pm_q75 >= 0 && fused->pm_q75 < nq && nq <= 5 &&
+                                 fused->pm_certain && fused->pm_uncertain;
+            fused->pm_done = 0;
+            if (want_pm)
+                hipLaunchKernelGGL(premask_bounds_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, st, m, nq, br, fused->pm_q25, fused->pm_q75,
+                                   fused->pm_factor, pm_thr, pm_bad);
+            int h_unfit4[4] = {0, 0, 0, 0};                                // unfit | producer flags (2) | premask bounds unfit
+            Q_TRY(hipMemcpyAsync(h_unfit4, unfit, sizeof h_unfit4, hipMemcpyDeviceToHost, st));
             Q_TRY(hipStreamSynchronize(st));
+            const int h_unfit = h_unfit4[0];
+            const bool use_pm = want_pm && h_unfit4[3] == 0;
             if (h_unfit) {
                 *fused_ok = 0;
                 return cleanup(PEM_OK);
@@ -1344,13 +1395,19 @@ static int quantiles_impl(size_t n, int m, const double* data, size_t ld, size_t
             cio.rec_count = rec_count;
             cio.cap = rcap;
             cio.flags = prod_flags;
+            if (use_pm) {
+                cio.premask = pm_thr;
+                cio.row_certain = fused->pm_certain;
+                cio.row_uncertain = fused->pm_uncertain;
+                fused->pm_done = 1;
+            }
             if (int rc = fused->count(cio, st)) return cleanup(rc);
             static pem::LdsAttrOnce attr;
-            Q_TRY(attr.ensure(reinterpret_cast<const void*>(record_hist_kernel), 150 * 1024));       // (+ its static tables)
+            Q_TRY(attr.ensure(reinterpret_cast<const void*>(record_hist_kernel), 148 * 1024));       // (+ 12 KB of static tables)
             int cus = 256;
             Q_TRY(pem::device_cus(&cus));
             hipLaunchKernelGGL(record_hist_kernel, dim3((unsigned)cus), blk, (size_t)m * nq * binsA * 4, st, rec_buf, rec_count, rcap, fused_waves, br,
-                               m * nq, binsA, histA);
+                               m * nq, nq, binsA, histA);
         }
         hipLaunchKernelGGL(decide_bracket_kernel, dim3((unsigned)(m * nt)), dim3(64), 0, st, nt, col, br, below, histA, binsA, tg, outside);
         hipLaunchKernelGGL(layout_kernel, dim3(1), dim3(64 * MAX_NC), 0, st, m, nt, tg, total);
@@ -1376,7 +1433,7 @@ static int quantiles_impl(size_t n, int m, const double* data, size_t ld, size_t
             } else {
                 int cus = 256;
                 Q_TRY(pem::device_cus(&cus));
-                hipLaunchKernelGGL(record_compact_kernel, dim3((unsigned)(cus * 2)), blk, 0, st, rec_buf, rec_count, rcap, fused_waves, br, m * nq, tg, cand);
+                hipLaunchKernelGGL(record_compact_kernel, dim3((unsigned)(cus * 2)), blk, 0, st, rec_buf, rec_count, rcap, fused_waves, br, m * nq, nq, tg, cand);
             }
             hipLaunchKernelGGL(select_kernel, dim3((unsigned)(m * nt)), blk, 0, st, nt, tg, cand, incomplete);
             Q_TRY(hipGetLastError());

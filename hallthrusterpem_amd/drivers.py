@@ -329,11 +329,12 @@ def forward_uq_statistics(n: int, seed: int = 0, keep_profile: bool = True, perc
     not read back for its percentiles (five reads of 7.3 GB per 1e7 samples in round 3; one, for the masks, now) and with
     `keep_profile=False` it is never written at all.
 
-    Returns the dictionary of `forward_uq` plus 'nan_idx', 'outlier_idx' (per output variable, as `filter_outputs`; the profile's
-    masks only when it is kept) and 'bands' ({name: (len(percentiles), ...)} as `percentile_bands`), every number equal to numpy's
-    on the same samples bit for bit.  'fused': whether the on-chip selection answered (heavy ties or a non-finite profile value
-    make it decline: the percentiles then come from passes over the stored profile -- evaluated again with the profile kept when
-    `keep_profile=False`)."""
+    Returns the dictionary of `forward_uq` plus 'nan_idx', 'outlier_idx' (per output variable, as `filter_outputs`, the profile's
+    included whether it is kept or not) and 'bands' ({name: (len(percentiles), ...)} as `percentile_bands`), every number equal to
+    numpy's on the same samples bit for bit.  'fused': whether the on-chip selection answered (heavy ties or a non-finite
+    profile value make it decline: the percentiles then come from passes over the stored profile -- evaluated again with the
+    profile kept when `keep_profile=False`); 'premasked': whether the profile's outlier mask was counted by the evaluation launch
+    too (against intervals for the IQR bounds, the few undecided samples settled afterwards) instead of by a pass over the profile."""
     import ctypes as C
     import torch
     from . import _lib, constants
@@ -342,22 +343,27 @@ def forward_uq_statistics(n: int, seed: int = 0, keep_profile: bool = True, perc
     pct = [25.0, 75.0] + [float(x) for x in percentiles]
     if len(pct) > MAX_Q:
         raise ValueError(f'at most {MAX_Q - 2} percentiles besides the quartiles')
-    answered, qj = False, None
+    answered, premasked, qj, certain, uncertain = False, False, None, None, None
+    thresh = int(0.75 * _lib.NANGLE)
     with torch.cuda.device(batch.device):
         stream = torch.cuda.current_stream(batch.device)
         if fused and n >= FUSED_STATS_MIN_N:
             rp, rn, gm = _linear_ranks(n, pct)
             qj = torch.empty((len(pct), _lib.NANGLE), dtype=torch.float64, device=batch.device)
             pilot = None if keep_profile else torch.empty(((n + 31) // 32, _lib.NANGLE), dtype=torch.float64, device=batch.device)
-            ok = C.c_int(0)
+            certain = torch.empty(n, dtype=torch.uint8, device=batch.device)
+            uncertain = torch.empty(n, dtype=torch.uint8, device=batch.device)
+            ok, pm_ok = C.c_int(0), C.c_int(0)
             ptr = lambda arr: C.c_void_p(arr.ctypes.data)                                       # noqa: E731
             outs = batch._out_ptrs
             _lib.check(_lib.load().pem_coupled_mc_stats_f64_dev(
                 n, 0, design.seed, design.stream, ptr(design.kind), ptr(design.a), ptr(design.b), constants.TORR_2_PA, batch.radius,
                 C.c_void_p(batch.inputs.data_ptr()) if keep_inputs else None, batch.inputs.stride(0),
                 outs[0], outs[1], outs[2], outs[3], None if pilot is None else C.c_void_p(pilot.data_ptr()), outs[4], outs[5], outs[6],
-                len(pct), ptr(rp), ptr(rn), ptr(gm), C.c_void_p(qj.data_ptr()), C.byref(ok), C.c_void_p(stream.cuda_stream)))
-            answered = bool(ok.value)
+                len(pct), ptr(rp), ptr(rn), ptr(gm), C.c_void_p(qj.data_ptr()), C.byref(ok),
+                0, 1, float(iqr_factor), C.c_void_p(certain.data_ptr()), C.c_void_p(uncertain.data_ptr()), C.byref(pm_ok),
+                C.c_void_p(stream.cuda_stream)))
+            answered, premasked = bool(ok.value), bool(pm_ok.value)
             del pilot
         else:
             batch.run_mc(design, first_index=0, write_inputs=keep_inputs)
@@ -367,6 +373,7 @@ def forward_uq_statistics(n: int, seed: int = 0, keep_profile: bool = True, perc
         out['x'] = batch.inputs
     if keep_profile:
         out['j_ion'] = batch.j_ion
+    full = None
     if not answered:                         # the passes over the stored profile
         if keep_profile:
             qj = column_percentiles(batch.j_ion, pct)
@@ -374,21 +381,53 @@ def forward_uq_statistics(n: int, seed: int = 0, keep_profile: bool = True, perc
             full = CoupledBatch(n, device=device, profile=True, thruster_qoi=False)
             full.run_mc(design, first_index=0)
             qj = column_percentiles(full.j_ion, pct)
-            del full
     qs = column_percentiles(batch.qoi.T, pct)                      # the three scalar QoIs in one selection
     q = {k: qs[:, i] for i, k in enumerate(QOI_NAMES)}
     q['j_ion'] = qj
     nan_idx, outlier_idx, bands = {}, {}, {}
-    for k in list(QOI_NAMES) + (['j_ion'] if keep_profile else []):
-        a, qk = out[k], q[k]
-        per_sample = int(np.prod(a.shape[1:])) if a.dim() > 1 else 1
-        iqr = qk[1] - qk[0]
-        nan_idx[k], count = _row_masks(a, qk[0] - iqr_factor * iqr, qk[1] + iqr_factor * iqr, per_sample)
-        outlier_idx[k] = count > int(0.75 * per_sample)
+    for k in QOI_NAMES:
+        iqr = q[k][1] - q[k][0]
+        nan_idx[k], count = _row_masks(out[k], q[k][0] - iqr_factor * iqr, q[k][1] + iqr_factor * iqr, 1)
+        outlier_idx[k] = count > 0
+    # the profile's masks (gen_data.py:160-168): NaN per sample, more than int(0.75 * 91) values outside [p25 - f iqr, p75 + f iqr]
+    iqr = qj[1] - qj[0]
+    lo, hi = qj[0] - iqr_factor * iqr, qj[1] + iqr_factor * iqr
+    if premasked:
+        # counted by the evaluation launch against INTERVALS for the bounds: a sample is settled unless its uncertain values could
+        # change the verdict -- those few (none, as a rule) are looked at again with the exact bounds
+        c, u = certain.to(torch.int32), uncertain.to(torch.int32)
+        outl = c > thresh
+        open_rows = torch.nonzero((~outl) & (c + u > thresh)).flatten()
+        if open_rows.numel():
+            rows = batch.j_ion[open_rows] if keep_profile else _profile_rows(design, open_rows, device=batch.device)
+            outl[open_rows] = ((rows < lo) | (rows > hi)).sum(dim=1) > thresh
+        nan_idx['j_ion'] = torch.zeros(n, dtype=torch.bool, device=batch.device)     # (a non-finite value makes the selection decline)
+        outlier_idx['j_ion'] = outl
+    else:
+        prof = batch.j_ion if keep_profile else (full.j_ion if full is not None else None)
+        if prof is None:                     # answered on chip but no premask (bounds it cannot take): the profile once, for the masks
+            full = CoupledBatch(n, device=device, profile=True, thruster_qoi=False)
+            full.run_mc(design, first_index=0)
+            prof = full.j_ion
+        nan_idx['j_ion'], count = _row_masks(prof, lo, hi, _lib.NANGLE)
+        outlier_idx['j_ion'] = count > thresh
+    del full
     for k in q:
         bands[k] = q[k][2:]
-    out.update(nan_idx=nan_idx, outlier_idx=outlier_idx, bands=bands, fused=answered)
+    out.update(nan_idx=nan_idx, outlier_idx=outlier_idx, bands=bands, fused=answered, premasked=premasked)
     return out
+
+
+def _profile_rows(design, indices, device=None):
+    """The profile rows of global samples `indices` (a CUDA index tensor) of the Monte-Carlo design, evaluated one by one -- the few
+    samples a campaign without a stored profile has to look at again."""
+    import torch
+    rows = []
+    one = CoupledBatch(2, device=device, profile=True, thruster_qoi=False)
+    for i in indices.tolist():
+        one.run_mc(design, first_index=int(i), count=1)
+        rows.append(one.j_ion[0].clone())
+    return torch.stack(rows)
 
 
 def generate_data(system, description: str, num_samples: int = 500, executor=None, verbose: bool = False,

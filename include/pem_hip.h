@@ -316,12 +316,19 @@ int pem_quantiles_last_path(void);
  * when j_ion is given).  *fused_ok = 1: q_out equals np.percentile of the profile bit for bit.  *fused_ok = 0: the selection
  * declined -- brackets of one key or overlapping (heavy ties), a rank outside its bracket, a non-finite profile value, record
  * overflow -- q_out is not written; all other outputs are complete either way, and the caller takes pem_quantiles_f64_dev over
- * the stored profile.  n >= PEM_MC_STATS_MIN_N.  Synchronises the stream.                                                          */
+ * the stored profile.  n >= PEM_MC_STATS_MIN_N.  Synchronises the stream.
+ * The premask (row_certain / row_uncertain [n] bytes on the device and premask_ok non-NULL, nq <= 5): quantiles q25 and q75 of the
+ * call are the quartiles of gen_data.py:163-164; the outlier bounds p25 - f iqr, p75 + f iqr are then known to lie in intervals
+ * (the quartiles lie in their brackets), and the counting launch also writes, per sample, how many of its 91 values lie outside
+ * the bounds FOR CERTAIN and how many are UNCERTAIN (inside one of the two intervals).  certain > int(0.75 * 91) is an outlier,
+ * certain + uncertain <= that is not, and the caller settles the rest from the exact bounds: gen_data.py:166-168 without a pass
+ * over the profile.  *premask_ok = 0: not produced (bounds zero or not finite, f < 0, nq > 5, or the selection declined).            */
 #define PEM_MC_STATS_MIN_N 4096
 int pem_coupled_mc_stats_f64_dev(size_t n, uint64_t first_index, uint64_t seed, uint32_t stream_id, const int32_t* kind, const double* a,
                                  const double* b, double torr2pa, double radius, double* x_out, size_t ld, double* V_cc, double* I_B0,
                                  double* T, double* j_ion, double* pilot_rows, double* div_angle, double* T_c, uint8_t* invalid, int nq,
                                  const uint64_t* rank_prev, const uint64_t* rank_next, const double* gamma, double* q_out, int* fused_ok,
+                                 int q25, int q75, double iqr_factor, uint8_t* row_certain, uint8_t* row_uncertain, int* premask_ok,
                                  pem_stream_t stream);
 
 /* The per-sample masks of `_filter_outputs` (scripts/gen_data.py:150-168) for one output variable in one pass over it

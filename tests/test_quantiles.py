@@ -328,7 +328,7 @@ def test_fused_campaign_statistics_equal_numpy(n, keep):
     nan_a, outl_a = drivers.filter_outputs(dict(own, j_ion=ref['j_ion']))
     for k in got['nan_idx']:
         assert torch.equal(got['nan_idx'][k], nan_a[k]) and torch.equal(got['outlier_idx'][k], outl_a[k]), k
-    assert set(got['nan_idx']) == ({'V_cc', 'div_angle', 'T_c', 'j_ion'} if keep else {'V_cc', 'div_angle', 'T_c'})
+    assert set(got['nan_idx']) == {'V_cc', 'div_angle', 'T_c', 'j_ion'} and got['premasked'] is got['fused']
 
 
 def test_fused_campaign_statistics_decline_and_fall_back(monkeypatch):
@@ -349,9 +349,13 @@ def test_fused_campaign_statistics_decline_and_fall_back(monkeypatch):
     small = drivers.forward_uq_statistics(n, seed=6, keep_profile=True)
     monkeypatch.delenv('PEM_QUANTILE_RECORD_CAP')
     assert small['fused'] is False
-    ok = drivers.forward_uq_statistics(n, seed=6, keep_profile=True, percentiles=(0.0, 1.0, 99.0, 100.0))
-    assert ok['fused'] is True and torch.equal(ok['j_ion'], small['j_ion'])
-    assert np.array_equal(ok['bands']['j_ion'].cpu().numpy(), np.percentile(ok['j_ion'].cpu().numpy(), [0.0, 1.0, 99.0, 100.0], axis=0))
+    ext = drivers.forward_uq_statistics(n, seed=6, keep_profile=True, percentiles=(0.0, 1.0, 99.0, 100.0))
+    assert ext['fused'] is False                                                # (the brackets of 0 % and 1 % overlap)
+    assert np.array_equal(ext['bands']['j_ion'].cpu().numpy(), np.percentile(ext['j_ion'].cpu().numpy(), [0.0, 1.0, 99.0, 100.0], axis=0))
+    ok = drivers.forward_uq_statistics(n, seed=6, keep_profile=True, percentiles=(2.0, 40.0, 60.0, 98.0))
+    assert ok['fused'] is True and ok['premasked'] is False and torch.equal(ok['j_ion'], small['j_ion'])      # six brackets: no premask
+    assert np.array_equal(ok['bands']['j_ion'].cpu().numpy(), np.percentile(ok['j_ion'].cpu().numpy(), [2.0, 40.0, 60.0, 98.0], axis=0))
+    assert torch.equal(ok['outlier_idx']['j_ion'], small['outlier_idx']['j_ion'])
     assert np.array_equal(small['bands']['j_ion'].cpu().numpy(), np.percentile(ok['j_ion'].cpu().numpy(), [5.0, 50.0, 95.0], axis=0))
 
 

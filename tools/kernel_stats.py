@@ -31,8 +31,8 @@ def demangle(name: str) -> str:
 def assembly(src: Path, extra) -> str:
     tmp = Path(tempfile.mkdtemp(prefix='kstats_'))
     try:
-        cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', f'-I{ROOT / "include"}', f'-I{CSRC}',
-               str(src), '-o', str(tmp / 'k.so'), '-save-temps=obj', *extra]
+        cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', f'-I{ROOT / "include"}', f'-I{CSRC}',
+               str(src), '-o', str(tmp / 'k.o'), '-save-temps=obj', *extra]
         subprocess.run(cmd, check=True, capture_output=True)
         return next(tmp.glob('*gfx950.s')).read_text()
     finally:
