@@ -38,8 +38,9 @@ Prints ONE JSON line on rank 0 with the fields the driver expects plus
                   NumPy rate from BASELINE.md (measured in the build container, not on this host) beside it;
   config.full_config (N = 1): the whole 1e7-sample configs[2] campaign as ONE launch on this GPU, measured in the
                   same run (8.7 GB of algorithmic traffic per pass).
-  config.campaign (N = 1): the sampling loop around the hot path at configs[2] size, stage by stage -- sample + evaluate,
-                  NaN / IQR masks, 5 / 50 / 95 % bands (outside the timed region).
+  config.campaign (N = 1): the sampling loop around the hot path at configs[2] size -- sample + evaluate, NaN / IQR masks,
+                  5 / 50 / 95 % bands -- as one fused call (total_ms; no_profile_total_ms) and as separate calls (outside the
+                  timed region).
   --fp32 adds the config-5 report: the fp32-arithmetic reduced-QoI kernel against the fp64 one on identical inputs.
 """
 import argparse
@@ -204,11 +205,11 @@ def full_config_pass(n, seed, lanes, layout='soa'):
 
 
 def campaign_report(n, seed):
-    """One forward-UQ campaign of `n` samples on this GPU, stage by stage (N = 1 only, outside the timed region): the sampling
-    loop around the hot path -- sample + evaluate with the profile kept (drivers.forward_uq), the NaN / IQR masks of
-    gen_data.py:125-174 (drivers.filter_outputs) and the 5 / 50 / 95 % bands of monte_carlo.py:363-658
-    (drivers.percentile_bands).  Best wall time of three calls after 30 ms of the same calls, results on the device.  Never lets the line down: an
-    exception is reported in its place."""
+    """One forward-UQ campaign of `n` samples on this GPU (N = 1 only, outside the timed region): the sampling loop around the
+    hot path -- sample + evaluate, the NaN / IQR masks of gen_data.py:125-174 and the 5 / 50 / 95 % bands of
+    monte_carlo.py:363-658 -- as one fused driver call (drivers.forward_uq_statistics) with and without a stored profile, and as
+    round 3's separate calls (drivers.forward_uq, filter_outputs, percentile_bands).  Best wall time of three calls after 30 ms
+    of the same calls, results on the device.  Never lets the line down: an exception is reported in its place."""
     import torch
     try:
         from hallthrusterpem_amd import drivers
@@ -230,16 +231,32 @@ def campaign_report(n, seed):
                 del r
             return t_best
 
+        # the campaign as ONE driver call (round 4): the profile's percentiles counted inside the evaluation launch, the outlier
+        # counts with them (drivers.forward_uq_statistics / pem_coupled_mc_stats_f64_dev) -- with the profile kept, and without
+        t_fused = best(lambda: drivers.forward_uq_statistics(n, seed=seed, keep_profile=True))
+        r = drivers.forward_uq_statistics(n, seed=seed, keep_profile=True)
+        flags = {'fused': bool(r['fused']), 'premasked': bool(r['premasked'])}
+        del r
+        torch.cuda.empty_cache()
+        t_fused_np = best(lambda: drivers.forward_uq_statistics(n, seed=seed, keep_profile=False))
+        torch.cuda.empty_cache()
+        # the same campaign as three calls over a stored profile (round 3's form; five quantiles now share one selection)
         t_model = best(lambda: drivers.forward_uq(n, seed=seed, keep_profile=True))
         out = drivers.forward_uq(n, seed=seed, keep_profile=True)
         keep = {k: out[k] for k in ('V_cc', 'div_angle', 'T_c', 'j_ion')}
         t_masks = best(lambda: drivers.filter_outputs(keep))
         t_bands = best(lambda: drivers.percentile_bands(out))
-        total = t_model + t_masks + t_bands
-        rec = {'samples': n, 'forward_uq_ms': 1e3 * t_model, 'filter_outputs_ms': 1e3 * t_masks, 'percentile_bands_ms': 1e3 * t_bands,
-               'total_ms': 1e3 * total, 'samples_per_s': n / total,
-               'note': 'sample + evaluate (profile kept), NaN / IQR masks, 5/50/95 % bands of every output; wall time per stage, '
-                       'best of three; exact percentiles (equal to numpy bit for bit)'}
+        t_stats = best(lambda: drivers.campaign_statistics(keep))
+        rec = {'samples': n, 'total_ms': 1e3 * t_fused, 'samples_per_s': n / t_fused,
+               'no_profile_total_ms': 1e3 * t_fused_np, 'no_profile_samples_per_s': n / t_fused_np, **flags,
+               'separate_calls': {'forward_uq_ms': 1e3 * t_model, 'filter_outputs_ms': 1e3 * t_masks, 'percentile_bands_ms': 1e3 * t_bands,
+                                  'total_ms': 1e3 * (t_model + t_masks + t_bands),
+                                  'campaign_statistics_ms': 1e3 * t_stats, 'total_one_selection_ms': 1e3 * (t_model + t_stats)},
+               'note': 'one forward-UQ campaign: sample + evaluate, NaN / IQR masks and 5/50/95 % bands of every output, wall time, best of '
+                       'three, every percentile equal to numpy bit for bit.  total_ms: drivers.forward_uq_statistics with the profile kept '
+                       '(percentiles and outlier counts of the profile taken inside the evaluation launch); no_profile_total_ms: the same, '
+                       'profile never written; separate_calls: forward_uq + filter_outputs + percentile_bands over the stored profile '
+                       '(round 3), and with the five quantiles of a variable in one selection (campaign_statistics)'}
         del out, keep
         torch.cuda.empty_cache()
         return rec

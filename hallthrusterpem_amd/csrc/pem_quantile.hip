@@ -932,23 +932,35 @@ __global__ void premask_bounds_kernel(int m, int nq, const Bracket* __restrict__
 constexpr int REC_LISTS_MAX = 64 * 2 * PEM_QUANTILE_MAX_Q;     // (column, quantile) pairs the record kernels keep a table of (m <= 128)
 
 // the list (column * nq + quantile) of a record: the bracket of its column whose high words hold the key's (they do not overlap)
-__device__ __forceinline__ int record_list(const uint4* __restrict__ s_br, int nq, const pem::Record& e, unsigned& t) {
+template <int NQ>
+__device__ __forceinline__ int record_list(const uint4* __restrict__ s_br, const pem::Record& e, unsigned& t, unsigned& mult, bool& none) {
     const unsigned kh = (unsigned)(e.key >> 32);
-    const int c0 = (int)e.col * nq;
+    const int c0 = (int)e.col * NQ;
     int cq = c0;
-    t = kh - s_br[c0].x;
-    for (int q = 1; q < nq; ++q) {
-        const unsigned tq = kh - s_br[c0 + q].x;
-        if (tq <= s_br[c0 + q].y) {
+    uint4 b[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) b[q] = s_br[c0 + q];
+    t = kh - b[0].x;
+    mult = b[0].z;
+    none = t > b[0].y;
+#pragma unroll
+    for (int q = 1; q < NQ; ++q) {
+        const unsigned tq = kh - b[q].x;
+        if (tq <= b[q].y) {
             cq = c0 + q;
             t = tq;
+            mult = b[q].z;
+            none = false;
         }
     }
     return cq;
 }
 
+constexpr int REC_UNROLL = 4;   // records a thread has in flight
+
+template <int NQ>
 __global__ __launch_bounds__(QBLOCK) void record_hist_kernel(const pem::Record* __restrict__ rec, const unsigned* __restrict__ rec_count, unsigned cap,
-                                                              unsigned waves, const Bracket* __restrict__ br, int lists, int nq, int bins,
+                                                              unsigned waves, const Bracket* __restrict__ br, int lists, int bins,
                                                               unsigned* __restrict__ hist) {
     extern __shared__ unsigned lds_hist[];                      // [lists][bins]
     __shared__ uint4 s_br[REC_LISTS_MAX];                       // {loh, words, mult, -}
@@ -958,12 +970,18 @@ __global__ __launch_bounds__(QBLOCK) void record_hist_kernel(const pem::Record* 
     for (unsigned w = blockIdx.x; w < waves; w += gridDim.x) {
         const unsigned cnt = rec_count[w] < cap ? rec_count[w] : cap;
         const pem::Record* r = rec + (size_t)w * cap;
-        for (unsigned i = threadIdx.x; i < cnt; i += QBLOCK) {
-            const pem::Record e = r[i];
-            unsigned t;
-            const int cq = record_list(s_br, nq, e, t);
-            if (t > s_br[cq].y) continue;                       // (not a value of any bracket: a NaN's bits -- the producer has flagged the run)
-            atomicAdd(&lds_hist[cq * bins + (int)__umulhi(t, s_br[cq].z)], 1u);
+        for (unsigned i0 = threadIdx.x; i0 < cnt; i0 += QBLOCK * REC_UNROLL) {
+            pem::Record e[REC_UNROLL];
+#pragma unroll
+            for (int u = 0; u < REC_UNROLL; ++u) e[u] = r[i0 + u * QBLOCK < cnt ? i0 + u * QBLOCK : i0];
+#pragma unroll
+            for (int u = 0; u < REC_UNROLL; ++u) {
+                unsigned t, mult;
+                bool none;
+                const int cq = record_list<NQ>(s_br, e[u], t, mult, none);
+                // (none: not a value of any bracket -- a NaN's bits; the producer has flagged the run)
+                if (!none && i0 + u * QBLOCK < cnt) atomicAdd(&lds_hist[cq * bins + (int)__umulhi(t, mult)], 1u);
+            }
         }
     }
     __syncthreads();
@@ -973,8 +991,9 @@ __global__ __launch_bounds__(QBLOCK) void record_hist_kernel(const pem::Record* 
     }
 }
 
+template <int NQ>
 __global__ __launch_bounds__(QBLOCK) void record_compact_kernel(const pem::Record* __restrict__ rec, const unsigned* __restrict__ rec_count, unsigned cap,
-                                                                 unsigned waves, const Bracket* __restrict__ br, int lists, int nq, Target* __restrict__ tg,
+                                                                 unsigned waves, const Bracket* __restrict__ br, int lists, Target* __restrict__ tg,
                                                                  u64* __restrict__ cand) {
     __shared__ uint4 s_br[REC_LISTS_MAX];                       // {loh, words, mult, -}
     __shared__ int2 s_bin[REC_LISTS_MAX];                       // the sub-bins the quantile's two targets collect (-1: not a list owner)
@@ -987,17 +1006,23 @@ __global__ __launch_bounds__(QBLOCK) void record_compact_kernel(const pem::Recor
     for (unsigned w = blockIdx.x; w < waves; w += gridDim.x) {
         const unsigned cnt = rec_count[w] < cap ? rec_count[w] : cap;
         const pem::Record* r = rec + (size_t)w * cap;
-        for (unsigned i = threadIdx.x; i < cnt; i += QBLOCK) {
-            const pem::Record e = r[i];
-            unsigned t;
-            const int cq = record_list(s_br, nq, e, t);
-            if (t > s_br[cq].y) continue;
-            const int bin = (int)__umulhi(t, s_br[cq].z);
-            const int2 want = s_bin[cq];
-            const int hit = want.x == bin ? 0 : (want.y == bin ? 1 : -1);
-            if (hit >= 0) {
-                Target& T = tg[2 * cq + hit];
-                cand[T.offset + atomicAdd(&T.cursor, 1ull)] = e.key;
+        for (unsigned i0 = threadIdx.x; i0 < cnt; i0 += QBLOCK * REC_UNROLL) {
+            pem::Record e[REC_UNROLL];
+#pragma unroll
+            for (int u = 0; u < REC_UNROLL; ++u) e[u] = r[i0 + u * QBLOCK < cnt ? i0 + u * QBLOCK : i0];
+#pragma unroll
+            for (int u = 0; u < REC_UNROLL; ++u) {
+                unsigned t, mult;
+                bool none;
+                const int cq = record_list<NQ>(s_br, e[u], t, mult, none);
+                if (none || i0 + u * QBLOCK >= cnt) continue;
+                const int bin = (int)__umulhi(t, mult);
+                const int2 want = s_bin[cq];
+                const int hit = want.x == bin ? 0 : (want.y == bin ? 1 : -1);
+                if (hit >= 0) {
+                    Target& T = tg[2 * cq + hit];
+                    cand[T.offset + atomicAdd(&T.cursor, 1ull)] = e[u].key;
+                }
             }
         }
     }
@@ -1145,7 +1170,10 @@ static int quantiles_impl(size_t n, int m, const double* data, size_t ld, size_t
     long long pilot = 32, pilot_min = 1 << 25;
     if (const char* e = getenv("PEM_QUANTILE_PILOT")) pilot = atoll(e);
     if (const char* e = getenv("PEM_QUANTILE_PILOT_MIN")) pilot_min = atoll(e);
-    if (fused) pilot = 32;                                                // (the producer wrote rows 0 .. ceil(n / 32) - 1)
+    if (fused) {                                                          // (the producer writes rows 0 .. ceil(n / 32) - 1 at most)
+        pilot = 32;
+        if (const char* e = getenv("PEM_FUSED_PILOT")) pilot = atoll(e) >= 32 ? atoll(e) : 32;
+    }
     const bool use_pilot = fused ? true : (pilot >= 2 && (long long)n * m >= pilot_min && (long long)n >= 4 * pilot);
     if (fused && (long long)n < 4 * pilot) return pem::fail(PEM_ERR_INVALID_ARG, "pem_quantiles: the fused form needs at least %lld rows", 4 * pilot);
 
@@ -1402,12 +1430,24 @@ static int quantiles_impl(size_t n, int m, const double* data, size_t ld, size_t
                 fused->pm_done = 1;
             }
             if (int rc = fused->count(cio, st)) return cleanup(rc);
-            static pem::LdsAttrOnce attr;
-            Q_TRY(attr.ensure(reinterpret_cast<const void*>(record_hist_kernel), 148 * 1024));       // (+ 12 KB of static tables)
             int cus = 256;
             Q_TRY(pem::device_cus(&cus));
-            hipLaunchKernelGGL(record_hist_kernel, dim3((unsigned)cus), blk, (size_t)m * nq * binsA * 4, st, rec_buf, rec_count, rcap, fused_waves, br,
-                               m * nq, nq, binsA, histA);
+#define Q_RECHIST(NQ_)                                                                                                       \
+    do {                                                                                                                     \
+        static pem::LdsAttrOnce attr;                                                                                        \
+        Q_TRY(attr.ensure(reinterpret_cast<const void*>(record_hist_kernel<NQ_>), 148 * 1024)); /* (+ 12 KB of static tables) */ \
+        hipLaunchKernelGGL(record_hist_kernel<NQ_>, dim3((unsigned)cus), blk, (size_t)m * nq * binsA * 4, st, rec_buf, rec_count, rcap, fused_waves, \
+                           br, m * nq, binsA, histA);                                                                        \
+    } while (0)
+            switch (nq) {
+                case 1: Q_RECHIST(1); break;
+                case 2: Q_RECHIST(2); break;
+                case 3: Q_RECHIST(3); break;
+                case 4: Q_RECHIST(4); break;
+                case 5: Q_RECHIST(5); break;
+                default: Q_RECHIST(6); break;
+            }
+#undef Q_RECHIST
         }
         hipLaunchKernelGGL(decide_bracket_kernel, dim3((unsigned)(m * nt)), dim3(64), 0, st, nt, col, br, below, histA, binsA, tg, outside);
         hipLaunchKernelGGL(layout_kernel, dim3(1), dim3(64 * MAX_NC), 0, st, m, nt, tg, total);
@@ -1433,7 +1473,17 @@ static int quantiles_impl(size_t n, int m, const double* data, size_t ld, size_t
             } else {
                 int cus = 256;
                 Q_TRY(pem::device_cus(&cus));
-                hipLaunchKernelGGL(record_compact_kernel, dim3((unsigned)(cus * 2)), blk, 0, st, rec_buf, rec_count, rcap, fused_waves, br, m * nq, nq, tg, cand);
+#define Q_RECCOMPACT(NQ_) \
+    hipLaunchKernelGGL(record_compact_kernel<NQ_>, dim3((unsigned)(cus * 2)), blk, 0, st, rec_buf, rec_count, rcap, fused_waves, br, m * nq, tg, cand)
+                switch (nq) {
+                    case 1: Q_RECCOMPACT(1); break;
+                    case 2: Q_RECCOMPACT(2); break;
+                    case 3: Q_RECCOMPACT(3); break;
+                    case 4: Q_RECCOMPACT(4); break;
+                    case 5: Q_RECCOMPACT(5); break;
+                    default: Q_RECCOMPACT(6); break;
+                }
+#undef Q_RECCOMPACT
             }
             hipLaunchKernelGGL(select_kernel, dim3((unsigned)(m * nt)), blk, 0, st, nt, tg, cand, incomplete);
             Q_TRY(hipGetLastError());
