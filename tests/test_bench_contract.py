@@ -73,7 +73,11 @@ def test_single_gpu_line_carries_the_whole_config():
     line = _one_json_line(out.stdout)
     camp = line['config']['campaign']                       # the sampling loop around the hot path, stage by stage
     assert 'error' not in camp and camp['samples'] == 300_000 and camp['samples_per_s'] > 1e6
-    assert abs(camp['total_ms'] - (camp['forward_uq_ms'] + camp['filter_outputs_ms'] + camp['percentile_bands_ms'])) < 1e-9
+    sep = camp['separate_calls']                            # round 3's three calls over a stored profile, and with one selection per variable
+    assert abs(sep['total_ms'] - (sep['forward_uq_ms'] + sep['filter_outputs_ms'] + sep['percentile_bands_ms'])) < 1e-9
+    assert sep['campaign_statistics_ms'] > 0 and sep['total_one_selection_ms'] > 0
+    # round 4: the campaign as ONE call, percentiles and outlier counts taken inside the evaluation launch; with and without a profile
+    assert camp['total_ms'] > 0 and camp['no_profile_total_ms'] > 0 and camp['fused'] is True and camp['premasked'] is True
     fc = line['config']['full_config']
     assert fc['samples'] == 2_000_000 and fc['bytes_per_launch'] == 872 * 2_000_000 and fc['value'] > 1e9
     assert abs(fc['frac_of_peak'] - fc['achieved_GBs'] / 8000.0) < 1e-12 and 0.3 < fc['frac_of_peak'] < 1.0
