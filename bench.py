@@ -58,7 +58,6 @@ sys.path.insert(0, str(ROOT))
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 SAMPLES_PER_GPU = 1_250_000    # BASELINE.json configs[2]: 1e7 coupled samples / 8 GPUs
 FULL_CONFIG_SAMPLES = 10_000_000
-REFERENCE_NUMPY_EVALS_PER_S = 1.4e5   # the reference's NumPy path, coupled, one core, build container
 
 
 def synth_inputs(batch, seed, rank, which=0):
@@ -89,6 +88,19 @@ def synth_inputs(batch, seed, rank, which=0):
         x[14] = u[14] * 7e-20 + 51e-20               # sigma_cex
         batch.load_soa(x, lo)                        # rows -> the batch's own input layout ('soa' or 'tile')
         del u, x
+
+
+def reference_numpy_baseline():
+    """The reference's own NumPy path as timed in the build container by tests/golden/time_reference.py (BASELINE.md section
+    3.1) -- replayed from the committed record, because the reference cannot travel to the GPU box."""
+    f = ROOT / 'profiles' / 'reference_numpy_baseline.json'
+    try:
+        rec = json.loads(f.read_text())
+        return {'value': float(rec['value']), 'unit': rec['unit'], 'cores': int(rec['cores']),
+                'source': f'replayed from profiles/{f.name} (written by {rec["generator"]} in the build container: {rec["what"]}; '
+                          f'{rec["samples"]} samples, best {rec["best_s"]:.2f} s on {rec["host"]["cpu"]})'}
+    except Exception as exc:
+        return {'value': None, 'unit': 'evals/s', 'cores': 1, 'source': f'none: profiles/{f.name} is missing or unreadable ({exc})'}
 
 
 def host_cpu_share():
@@ -127,9 +139,7 @@ def cpu_baseline(target_seconds=2.5):
     return {'value': n / best, 'unit': 'evals/s', 'cores': threads, 'kind': 'port',
             'sample': f'{n} coupled samples (same priors, fp64, 91 angles, full profile), best of 3 runs: '
                       f'{best:.2f} s wall on {threads} OpenMP threads',
-            'reference_numpy': {'value': REFERENCE_NUMPY_EVALS_PER_S, 'unit': 'evals/s', 'cores': 1,
-                                'source': 'BASELINE.md section 2: hallmd cathode_coupling + current_density (NumPy/SciPy), 1e5 samples, '
-                                          'measured in the build container (8 vCPU Xeon @2.1 GHz); the reference cannot travel to this host'}}
+            'reference_numpy': reference_numpy_baseline()}
 
 
 def kernel_source_hash():
@@ -163,6 +173,26 @@ def read_committed_traffic(n, layout='soa'):
         except Exception:
             continue
     return None, None, stale or 'no committed counter measurement of this launch size'
+
+
+def read_committed_trace(n, layout='soa'):
+    """Traced mean duration (us) of the coupled kernel from the newest committed rocprofv3 --kernel-trace summary of this launch
+    size and layout that was taken ON THE KERNEL SOURCES IN THE TREE (profiles/traffic_r*.json: `kernel_mean_us`, `kernel_srchash`):
+    (us, file name) or (None, why-not)."""
+    want = kernel_source_hash()
+    stale = None
+    for f in sorted((ROOT / 'profiles').glob('traffic_r*.json'), reverse=True):
+        try:
+            rec = json.loads(f.read_text())
+            if int(rec.get('samples_per_launch', -1)) != int(n) or rec.get('layout', 'soa') != layout:
+                continue
+            if rec.get('kernel_srchash') != want:
+                stale = stale or f'{f.name} was traced on other kernel sources (kernel_srchash {rec.get("kernel_srchash")}, tree {want})'
+                continue
+            return float(rec['kernel_mean_us']), f.name
+        except Exception:
+            continue
+    return None, stale or 'no committed trace of this launch size'
 
 
 def event_times(fn, reps):
@@ -480,6 +510,16 @@ def main():
             dt = float(t.item())
         return dt
 
+    # The driver's arguments taken literally, first: W warm-up steps and K timed steps from a cold start (no spin-up: the process
+    # has done nothing on the GPU but fill its inputs, and those fills ended a while ago) -- reported as config.value_no_spin_up
+    # beside `value`, which is the same K steps after the clock spin-up below.
+    elapsed_cold = None
+    if args.spin_up_ms > 0:
+        torch.cuda.synchronize()
+        time.sleep(0.05)                                  # (an idle period, as before a process's first launch)
+        for _ in range(args.warmup):
+            step()
+        elapsed_cold = timed(args.steps)
     # clock spin-up (see --spin-up-ms): plain steps, no fence between them and the warm-up steps that follow
     spin_steps = 0
     if args.spin_up_ms > 0:
@@ -577,8 +617,14 @@ def main():
         gather_desc = {'qoi': f'reduced QoIs (24 B/sample), {len(pipe.bounds) if pipe else 1} chunks per step, each all-gather overlapped with the next chunk\'s evaluation',
                        'once': 'reduced QoIs (24 B/sample), one all-gather per step, overlapped with the next step',
                        'full': '91-point profiles, one all-gather per step, overlapped with the next step'}.get(args.gather, 'none')
+        traced_us, traced_src = read_committed_trace(n, args.layout) if not (args.no_profile or args.mixed) else (None, 'kept for the fp64-profile launch only')
         line = {
             'metric': 'coupled PEM-v0 model evals/sec', 'value': world * n * args.steps / elapsed, 'unit': 'evals/s',
+            'value_methodology': (f'{args.steps} complete launches between two fences, dealt onto {args.streams} HIP stream(s)' +
+                                  (f', after {args.warmup} warm-up steps and an untimed clock spin-up of {args.spin_up_ms:g} ms; the same steps '
+                                   f'without the spin-up: config.value_no_spin_up; on one stream: config.single_stream' if args.spin_up_ms > 0 else
+                                   f', after {args.warmup} warm-up steps, no clock spin-up') +
+                                  '; rounds 1-2 reported the one-stream, no-spin-up figure'),
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64' if not args.mixed else 'f64 (profile stored as f32)', 'data': 'synthetic',
             'config': {'workload': 'coupled cathode->thruster(analytic test double)->plume forward UQ, '
@@ -589,6 +635,10 @@ def main():
                        'spin_up': {'steps': spin_steps, 'ms': args.spin_up_ms,
                                    'note': 'untimed steps before the W warm-up steps: the GPU reaches its steady clocks after about 15 ms '
                                            'of load (profiles/warmup_r03.txt); --spin-up-ms 0 times the ramp instead'},
+                       'value_no_spin_up': ({'value': world * n * args.steps / elapsed_cold, 'ms_per_step': 1e3 * elapsed_cold / args.steps,
+                                             'note': f'the same {args.warmup} warm-up + {args.steps} timed steps from a cold start, before the spin-up: what the '
+                                                     f'arguments mean taken literally (a run of a few dozen launches times the clock ramp, profiles/warmup_r03.txt)'}
+                                            if elapsed_cold else None),
                        'single_stream': ({'ms_per_step': 1e3 * elapsed_one_stream / args.steps, 'value': world * n * args.steps / elapsed_one_stream,
                                           'note': 'the same steps on ONE stream, every launch waiting for the one before'}
                                          if elapsed_one_stream else None),
@@ -603,7 +653,12 @@ def main():
                        'parallelism': f'sample-shard x{world}',
                        'invalid_fraction': frac_invalid},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'frac': achieved / HBM_PEAK_GBS,
+                         'frac_traced': (bytes_per_launch / (traced_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if traced_us else None,
+                         'frac_traced_source': (f'rocprofv3 --kernel-trace mean of this kernel, {traced_us:.1f} us per launch, from profiles/{traced_src} '
+                                                f'(same kernel sources: kernel_srchash {kernel_source_hash()}); not measured in this run')
+                                               if traced_us else f'none: {traced_src}',
+                         'traffic': traffic,
                          'traffic_source': (f'replayed from profiles/{traffic_file} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this '
                                             f'launch size, gfx950 corrections applied; same kernel sources, kernel_srchash {kernel_source_hash()}); '
                                             f'not measured in this run') if traffic else f'none: {traffic_why}',

@@ -91,7 +91,17 @@ def test_single_gpu_line_carries_the_whole_config():
         assert src.startswith('replayed from profiles/') and 'kernel_srchash' in src
         assert 0.9 * 872 * 1_250_000 < line['roofline']['traffic'] < 1.3 * 872 * 1_250_000
     cb = line['cpu_baseline']
-    assert cb['kind'] == 'port' and cb['reference_numpy']['value'] == 1.4e5 and cb['reference_numpy']['cores'] == 1
+    # the reference's own NumPy rate is replayed from the committed record of tests/golden/time_reference.py, not a literal
+    import json as _json
+    rec = _json.loads((ROOT / 'profiles' / 'reference_numpy_baseline.json').read_text())
+    assert cb['kind'] == 'port' and cb['reference_numpy']['value'] == rec['value'] and cb['reference_numpy']['cores'] == 1
+    assert 'replayed from profiles/reference_numpy_baseline.json' in cb['reference_numpy']['source'] and rec['generator'] == 'tests/golden/time_reference.py'
+    # the line is self-sufficient under the driver's literal arguments (round 4): the cold figure, the methodology, the traced fraction
+    cold = line['config']['value_no_spin_up']
+    assert cold['value'] > 0 and cold['ms_per_step'] > 0 and 'spin-up' in line['value_methodology']
+    assert 'frac_traced' in line['roofline'] and line['roofline']['frac_traced_source']
+    if line['roofline']['frac_traced'] is not None:
+        assert 0.3 < line['roofline']['frac_traced'] < 1.0 and 'kernel_srchash' in line['roofline']['frac_traced_source']
 
 
 def test_two_ranks_through_torch_distributed_run():
