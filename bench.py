@@ -294,6 +294,79 @@ def campaign_report(n, seed):
         return {'samples': n, 'error': f'{type(exc).__name__}: {exc}'}
 
 
+XGMI_LINK_GBS_PER_DIRECTION = 76.5   # MI355X_MICROARCH.md: 7 links x ~153 GB/s bidirectional per GPU
+
+
+def gather_explanation(world, n, bytes_per_sample, ms_eval, value, value_nogather, rate_1gpu_equiv):
+    """What DESIGN.md section 5 predicts for this run's exchange, beside what was measured: per step every rank receives
+    (world - 1) shards of `bytes_per_sample` x n bytes, spread at best over its 7 inbound xGMI links."""
+    recv = (world - 1) * n * bytes_per_sample
+    links = min(7, max(1, world - 1))
+    t_link_ms = recv / (links * XGMI_LINK_GBS_PER_DIRECTION * 1e9) * 1e3
+    t_step_pred = max(ms_eval, t_link_ms)                          # gather fully overlapped with the evaluation of the next piece
+    return {'bytes_received_per_rank_per_step': recv, 'bytes_sent_per_rank_per_step': n * bytes_per_sample,
+            'inbound_links_assumed': links, 'link_GBs_per_direction_assumed': XGMI_LINK_GBS_PER_DIRECTION,
+            'link_time_ms_predicted': t_link_ms, 'evaluation_ms_per_step': ms_eval,
+            'predicted_ms_per_step': t_step_pred, 'predicted_value': world * n / (t_step_pred * 1e-3),
+            'predicted_bound': 'xGMI links' if t_link_ms > ms_eval else 'evaluation kernel',
+            'measured_value': value, 'measured_value_without_gather': value_nogather,
+            'implied_inbound_GBs_per_rank': (recv / ((world * n / value)) / 1e9) if value else None,
+            'note': 'prediction of DESIGN.md section 5: a step cannot be shorter than the evaluation of the shard, nor than its inbound '
+                    'bytes over the links; near-linear scaling is expected of value_without_gather and of the reductions-only campaign, '
+                    'not of a per-sample gather once (world - 1) x 30 MB per step exceed what the links carry in one evaluation'}
+
+
+def reductions_campaign(n_total, seed, rank, world, group=None):
+    """The campaign that exchanges SUMS, not samples (the mode that can scale linearly): every rank
+    evaluates its shard of a forward-UQ campaign with the profile kept, the 5 / 50 / 95 % bands of every output are those
+    of ALL ranks' samples (drivers.percentile_bands(sharded=True): histograms all-reduced, a few hundred candidates per rank
+    gathered), and first-order / total Sobol' indices come from per-rank partial sums (one all-reduce of O(d n_qoi) doubles).
+    No per-sample all-gather.  Wall time of the slowest rank, outside the timed region."""
+    import torch
+    import torch.distributed as dist
+    from hallthrusterpem_amd import drivers
+    try:
+        def wall(fn):
+            if world > 1:
+                dist.barrier(group)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = fn()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+                dt = float(t.item())
+            return dt, r
+        wall(lambda: drivers.forward_uq(n_total, seed=seed, keep_profile=True, rank=rank, world=world, keep_inputs=False))   # warm
+        t_eval, out = wall(lambda: drivers.forward_uq(n_total, seed=seed, keep_profile=True, rank=rank, world=world, keep_inputs=False))
+        t_bands, bands = wall(lambda: drivers.percentile_bands(out, sharded=world > 1, group=group))
+        n_base = max(1024, n_total // 14)
+        t_sobol, sob = wall(lambda: drivers.sobol_indices(n_base, seed=seed, fixed={'P_b': 1e-5, 'V_a': 300.0, 'mdot_a': 5e-6}, group=group))
+        total = t_eval + t_bands + t_sobol
+        return {'samples': n_total, 'ranks': world, 'forward_uq_ms': 1e3 * t_eval, 'sharded_bands_ms': 1e3 * t_bands,
+                'sobol_ms': 1e3 * t_sobol, 'sobol_evaluations': sob['evaluations'], 'total_ms': 1e3 * total,
+                'samples_per_s': n_total / (t_eval + t_bands), 'sobol_evaluations_per_s': sob['evaluations'] / t_sobol,
+                'exchange': 'all-reduced histograms and min / max, all-gathered candidate lists (about 1 MB per rank), one all-reduce of the '
+                            'Sobol\' sums: no per-sample gather',
+                'median_band_of_T_c': float(bands['T_c'][1])}
+    except Exception as exc:
+        return {'samples': n_total, 'error': f'{type(exc).__name__}: {exc}'}
+
+
+def collective_library(backend):
+    """'RCCL x.y.z' (torch's nccl backend on ROCm) or the backend's name"""
+    try:
+        import torch
+        if backend == 'nccl':
+            v = torch.cuda.nccl.version()
+            return 'RCCL ' + '.'.join(str(x) for x in (v if isinstance(v, (tuple, list)) else (v,))) + f' (torch {torch.__version__}, backend nccl)'
+        return f'{backend} (torch {torch.__version__})'
+    except Exception as exc:
+        return f'{backend} (version unavailable: {exc})'
+
+
 def fp32_report(n, seed):
     """config 5's tolerance check: the fp32-arithmetic reduced-QoI kernel against the fp64 one on identical inputs."""
     from hallthrusterpem_amd.fp32 import compare_with_fp64
@@ -359,6 +432,9 @@ def main():
     ap.add_argument('--campaign-samples', type=int, default=FULL_CONFIG_SAMPLES,
                     help='N=1: also time one forward-UQ campaign of this many samples stage by stage -- sample + evaluate, NaN / IQR '
                          'masks, 5/50/95 %% bands (config.campaign; 0 = skip)')
+    ap.add_argument('--reductions-samples', type=int, default=-1,
+                    help='N>1: also time a campaign that exchanges sums instead of samples -- sharded percentile bands + Sobol\' indices, '
+                         'this many samples over all ranks (config.reductions_campaign; default: samples-per-gpu x N; 0 = skip)')
     ap.add_argument('--seed', type=int, default=2)
     ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL; default) or gloo (rehearsal on one GPU)')
     ap.add_argument('--oversubscribe', action='store_true',
@@ -555,6 +631,24 @@ def main():
         elapsed_nogather = timed(args.steps)
         use_gather[0] = True
 
+    # N > 1: every rank's own gather-free rate (the MAX over ranks above is the slowest one's): min / max over the ranks
+    per_rank_nogather = None
+    if multi and elapsed_nogather is not None:
+        fence()
+        t0 = time.perf_counter()
+        use_gather[0] = False
+        for _ in range(args.steps):
+            step()
+        drain()
+        torch.cuda.synchronize()
+        mine = n * args.steps / (time.perf_counter() - t0)
+        use_gather[0] = True
+        allr = [torch.zeros(1, dtype=torch.float64, device=batch.device) for _ in range(dist.get_world_size())]
+        dist.all_gather(allr, torch.tensor([mine], dtype=torch.float64, device=batch.device))
+        rates = [float(t.item()) for t in allr]
+        per_rank_nogather = {'min': min(rates), 'max': max(rates), 'ranks': len(rates),
+                             'note': 'evaluations/s of each rank alone over the same steps without the exchange (no barrier between ranks)'}
+
     # N > 1: what arrived is what was sent -- every rank re-evaluates every rank's seeded shard and compares bit for bit
     verified = None
     if gather_on and full_recv is None:
@@ -609,6 +703,11 @@ def main():
         fm, _ = event_times(fill, 40)
         write_stream = batches[0].j_ion.numel() * 8 / (fm * 1e-3) / 1e9
 
+    red = None
+    if multi and args.reductions_samples != 0 and not (args.no_profile or args.mixed):
+        n_red = args.reductions_samples if args.reductions_samples > 0 else world * n
+        red = reductions_campaign(n_red, args.seed, rank, world)           # (a collective: every rank takes part)
+
     if rank == 0:
         bytes_per_launch = batch.bytes_per_eval * n
         achieved = bytes_per_launch / (kern_mean_ms * 1e-3) / 1e9
@@ -650,6 +749,13 @@ def main():
                        'gather': gather_desc if gather_on else 'none',
                        'gathered_qoi_verified': verified,
                        'value_without_gather': (world * n * args.steps / elapsed_nogather) if elapsed_nogather else None,
+                       'value_without_gather_per_rank': per_rank_nogather,
+                       'ranks_seen': (dist.get_world_size() if multi else 1),
+                       'collective_library': collective_library(args.dist_backend) if multi else None,
+                       'gather_explained': (gather_explanation(world, n, 24 if args.gather != 'full' else 8 * 91,
+                                                               1e3 * (elapsed_nogather or elapsed) / args.steps, world * n * args.steps / elapsed,
+                                                               (world * n * args.steps / elapsed_nogather) if elapsed_nogather else None, None)
+                                            if gather_on else None),
                        'parallelism': f'sample-shard x{world}',
                        'invalid_fraction': frac_invalid},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -685,6 +791,8 @@ def main():
             line['config']['full_config'] = full_config_pass(args.full_config_samples, args.seed, lanes, args.layout)
         if world == 1 and not multi and args.campaign_samples > 0 and not (args.no_profile or args.mixed):
             line['config']['campaign'] = campaign_report(args.campaign_samples, args.seed)
+        if red is not None:
+            line['config']['reductions_campaign'] = red
         if args.fp32 and world == 1:
             line['fp32'] = fp32_report(n, args.seed)
         if world == 1 and not args.no_cpu_baseline:

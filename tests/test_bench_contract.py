@@ -119,6 +119,20 @@ def test_two_ranks_through_torch_distributed_run():
     assert line['cpu_baseline'] is None and line['config']['parallelism'] == 'sample-shard x2'
     # after the overlapped loop every rank compared what it received from every rank with a local re-evaluation
     assert line['config']['gathered_qoi_verified'] is True
+    # the line explains an N > 1 run by itself (round 4): who took part, what was exchanged, what the links allow, each rank's own rate
+    cfg = line['config']
+    assert cfg['ranks_seen'] == 2 and 'gloo' in cfg['collective_library']
+    pr = cfg['value_without_gather_per_rank']
+    assert pr['ranks'] == 2 and 0 < pr['min'] <= pr['max']
+    ge = cfg['gather_explained']
+    assert ge['bytes_sent_per_rank_per_step'] == 24 * 131072 and ge['bytes_received_per_rank_per_step'] == 24 * 131072
+    assert ge['predicted_bound'] in ('xGMI links', 'evaluation kernel') and ge['predicted_value'] > 0 and ge['measured_value'] == line['value']
+    assert abs(ge['predicted_ms_per_step'] - max(ge['link_time_ms_predicted'], ge['evaluation_ms_per_step'])) < 1e-12
+    # ... and carries the campaign that exchanges sums, not samples: sharded bands + Sobol' indices, no per-sample gather
+    red = cfg['reductions_campaign']
+    assert 'error' not in red, red
+    assert red['ranks'] == 2 and red['samples'] == 2 * 131072 and red['samples_per_s'] > 0 and red['sobol_evaluations'] >= 14 * 1024
+    assert 'no per-sample gather' in red['exchange'] and 0.0 < red['median_band_of_T_c'] < 1.0
 
 
 @pytest.mark.parametrize('gather', ['once', 'qoi'])
