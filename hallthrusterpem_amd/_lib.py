@@ -51,8 +51,10 @@ SIGNATURES = {
     'pem_svd_compress_f64_dev': (C.c_int, [_sz, C.c_int, C.c_int, C.c_int, _f8, _dp, _dp, _dp, _dp]),
     'pem_svd_reconstruct_f64_dev': (C.c_int, [_sz, C.c_int, C.c_int, C.c_int, _f8, _dp, _dp, _dp, _dp]),
     'pem_coupled_mc_f64_dev': (C.c_int, [_sz, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, _dp, _dp, _dp, _f8, _f8, _dp, _sz] + [_dp] * 7 + [_dp]),
-    'pem_sparse_predict_f64_dev': (C.c_int, [_sz, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _sz, _dp, _sz, _dp]),
-    'pem_sparse_grid_values_f64_dev': (C.c_int, [_sz, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _sz, _dp, _sz, _dp]),
+    'pem_sparse_predict_f64_dev': (C.c_int, [_sz, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _sz, _dp, _sz, C.c_int, C.c_int, _dp]),
+    'pem_sparse_grid_values_f64_dev': (C.c_int, [_sz, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _sz, _dp, _sz, C.c_int, C.c_int, _dp]),
+    'pem_sparse_predict_field_f64_dev': (C.c_int, [_sz, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _sz, _dp, _sz, C.c_int, C.c_int,
+                                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _dp, _dp, _dp]),
     'pem_key_minmax_f64_dev': (C.c_int, [_sz, C.c_int, _dp, _sz, _dp, _dp, _dp, _dp]),
     'pem_range_hist_f64_dev': (C.c_int, [_sz, C.c_int, _dp, _sz, C.c_int, _dp, _dp, C.c_int, _dp, _dp]),
     'pem_range_narrow_dev': (C.c_int, [C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp]),

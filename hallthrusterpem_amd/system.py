@@ -192,8 +192,14 @@ class PemV0System:
             v = np.broadcast_to(vals[d], shape).reshape(-1)
             u = (np.log10(v) if p.kind == LOGUNIFORM else v)
             t[d] = 2.0 * (u - p.a) / (p.b - p.a) - 1.0
-        y = s.predict(torch.from_numpy(t)).cpu().numpy()
-        return {k: y[i].reshape(shape) for i, k in enumerate(s.qoi)}
+        y = s.predict_fields(torch.from_numpy(t))
+        out = {k: y[k].cpu().numpy().reshape(shape) for k in s.scalars}
+        if s.field:                                          # the compressed field comes back reconstructed, with its coordinates
+            f = y[s.field].cpu().numpy()
+            out[s.field] = f.reshape(shape + (f.shape[-1],))
+            from .models.plume import _coords, angle_grid
+            out[f'{s.field}{COORDS_STR_ID}'] = _coords(shape, angle_grid())      # plume.py:153-157: every element the same alpha_rad array
+        return out
 
     # ----------------------------------------------------------------------------------------------------- training
     def fit(self, targets=None, max_iter: int = 20, max_tol: float = 1e-3, num_refine: int = 1000, varied=None,
@@ -204,9 +210,15 @@ class PemV0System:
         from .surrogate import SparseGridSurrogate
         fixed = dict(fixed or {})
         varied = tuple(varied) if varied is not None else tuple(k for k in COUPLED_INPUTS if k not in fixed)
-        qoi = tuple(targets) if targets else ('V_cc', 'div_angle', 'T_c')
+        # targets=None: every output the surrogate can carry, as the reference trains all of a system's outputs -- the scalars and
+        # j_ion through the latent coefficients of its SVD map (process_compression's, when it has run; else one fitted for the box)
+        qoi = tuple(targets) if targets else ('V_cc', 'div_angle', 'T_c', 'j_ion')
         if self.surrogate is None or self.surrogate.varied != varied or self.surrogate.qoi != qoi:
-            self.surrogate = SparseGridSurrogate(varied, fixed=fixed, priors=self.priors, qoi=qoi)
+            comp = None
+            if 'j_ion' in qoi and 'j_ion' in self._outputs and self._outputs['j_ion'].compression is not None \
+                    and self._outputs['j_ion'].compression.svd.basis is not None:
+                comp = self._outputs['j_ion'].compression.svd
+            self.surrogate = SparseGridSurrogate(varied, fixed=fixed, priors=self.priors, qoi=qoi, compression=comp)
         for _it in range(max_iter):
             hist = self.surrogate.refine(max_iter=1, num_refine=num_refine, seed=seed + len(self.train_history))
             if not hist:
@@ -216,8 +228,10 @@ class PemV0System:
             if test_set is not None:
                 xt, yt = test_set
                 pred = self._predict_surrogate(xt)
-                entry['test_error'] = {k: float(np.linalg.norm(pred[k] - np.asarray(yt[k])) / np.linalg.norm(np.asarray(yt[k])))
-                                       for k in qoi}
+                # relative L2 error per target (fit_surr.py:121-133 plots exactly this); a log10-normalised field in its norm
+                nrm = lambda k, v: np.log10(np.asarray(v, dtype=np.float64)) if k == 'j_ion' else np.asarray(v, dtype=np.float64)   # noqa: E731
+                entry['test_error'] = {k: float(np.linalg.norm(nrm(k, pred[k]) - nrm(k, yt[k])) / np.linalg.norm(nrm(k, yt[k])))
+                                       for k in qoi if k in yt}
             self.train_history.append(entry)
             if indicator < max_tol:
                 break
@@ -241,7 +255,11 @@ class PemV0System:
                  'surrogate': None if self.surrogate is None else
                  {'varied': self.surrogate.varied, 'fixed': self.surrogate.fixed, 'qoi': self.surrogate.qoi,
                   'index_set': self.surrogate.index_set, 'candidates': self.surrogate.candidates,
-                  'values': self.surrogate.values, 'model_evals': self.surrogate.model_evals}}
+                  'values': self.surrogate.values, 'model_evals': self.surrogate.model_evals,
+                  'max_active': self.surrogate.max_active, 'max_level': self.surrogate.max_level,
+                  'compression': None if self.surrogate.compression is None else
+                  {'rank': self.surrogate.compression.rank, 'basis': self.surrogate.compression.basis.cpu().numpy(),
+                   'relative_error': getattr(self.surrogate.compression, 'relative_error', None)}}}
         with open(path, 'wb') as fd:
             pickle.dump(state, fd)
         return path
@@ -258,9 +276,17 @@ class PemV0System:
         if state['surrogate'] is not None:
             from .surrogate import SparseGridSurrogate
             st = state['surrogate']
-            s = SparseGridSurrogate(st['varied'], fixed=st['fixed'], priors=self.priors, qoi=st['qoi'])
+            comp = None
+            if st.get('compression') is not None:
+                import torch
+                from .compression import SVDCompression
+                comp = SVDCompression(norm='log10', reconstruction_tol=0.01, rank=st['compression']['rank'])
+                comp.basis = torch.from_numpy(st['compression']['basis']).cuda()
+                comp.relative_error = st['compression']['relative_error']
+            s = SparseGridSurrogate(st['varied'], fixed=st['fixed'], priors=self.priors, qoi=st['qoi'], compression=comp,
+                                    max_active=st.get('max_active', 3), max_level=st.get('max_level', 3))
             s.index_set, s.candidates, s.values, s.model_evals = st['index_set'], st['candidates'], st['values'], st['model_evals']
-            s._tables = None
+            s.rebuild_device_tables()
             self.surrogate = s
         return self
 

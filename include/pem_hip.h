@@ -270,17 +270,30 @@ int pem_svd_reconstruct_f64_dev(size_t n, int dof, int rank, int norm, double no
  * index: [n_beta][2 + 2*PEM_SURR_MAX_ACTIVE] int32 = {n_active, value offset (rows), dims[], levels[]};
  * values: [rows][n_out]; t: [n_dim][ld] normalised coordinates in [-1, 1], n_dim <= PEM_SURR_MAX_DIM;
  * out: [n_out][ld_out]; n_out <= 16.                                                                        */
-#define PEM_SURR_MAX_ACTIVE 3
+#define PEM_SURR_MAX_ACTIVE 5
+#define PEM_SURR_MAX_LEVEL 4
 #define PEM_SURR_MAX_DIM 32
+/* max_active / max_level: the largest number of active dimensions / the highest level any multi-index of `index` has (the caller
+ * built the table): they size the LDS the kernel keeps the outer dimensions' bases in -- (max_active - 1) (2^max_level + 1) + n_dim
+ * doubles per thread of 256 must fit 160 KB.                                                                                          */
 int pem_sparse_predict_f64_dev(size_t n, int n_dim, int n_beta, const int32_t* index, const double* coef,
                                const double* values, int n_out, const double* t, size_t ld, double* out,
-                               size_t ld_out, pem_stream_t stream);
+                               size_t ld_out, int max_active, int max_level, pem_stream_t stream);
 /* The same tables, every grid on its own: out[b][o][i] = coef[b] * (the interpolant of grid b at point i), out: [n_beta][n_out]
  * [ld_out].  The adaptive refinement scores all its candidate index sets from ONE such launch -- a prediction is linear in the
  * combination coefficients, so each trial is a [n_beta] x [n_beta][n_out n] product of these values (surrogate.py refine). */
 int pem_sparse_grid_values_f64_dev(size_t n, int n_dim, int n_beta, const int32_t* index, const double* coef,
                                    const double* values, int n_out, const double* t, size_t ld, double* out,
-                                   size_t ld_out, pem_stream_t stream);
+                                   size_t ld_out, int max_active, int max_level, pem_stream_t stream);
+/* Prediction + reconstruction of a compressed field QoI in one launch (round 4): outputs lat0 .. lat0 + rank - 1 of the surrogate
+ * are the SVD latent coefficients the reference trains on (scripts/pem_v0/pem_v0_SPT-100.yml:273-280 `j_ion`: svd, log10 norm,
+ * reconstruction_tol 0.01; scripts/fit_surr.py:101-133), and field[i][k] = denorm(sum_q latent_q(i) basis[k][q]), k < dof, leaves
+ * with them -- what amisc's System.predict returns for such a variable, without pem_svd_reconstruct_f64_dev's second pass.
+ * norm / norm_scale / basis as pem_svd_reconstruct_f64_dev; field: [n][dof] row-major.                                            */
+int pem_sparse_predict_field_f64_dev(size_t n, int n_dim, int n_beta, const int32_t* index, const double* coef, const double* values,
+                                     int n_out, const double* t, size_t ld, double* out, size_t ld_out, int max_active, int max_level,
+                                     int lat0, int rank, int dof, int norm, double norm_scale, const double* basis, double* field,
+                                     pem_stream_t stream);
 
 /* ---- per-column order statistics over the sample axis -------------------------------------------------------------
  * The percentiles of scripts/gen_data.py:125-174 (`np.percentile(arr, 25 | 75, axis=0)`, NaN / interquartile-range masks) and

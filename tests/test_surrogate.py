@@ -125,13 +125,13 @@ def test_predict_kernel_synthetic_tables_all_output_widths(n_out):
     coefs = {b: float(c) for b, c in zip(betas, rng.integers(-3, 4, len(betas)))}
     coefs[betas[0]] = 1.0
     used = [b for b in betas if coefs[b] != 0]
-    idx = np.zeros((len(used), 8), dtype=np.int32)
+    idx = np.zeros((len(used), 12), dtype=np.int32)                          # {n_active, first row, dims[5], levels[5]} (PEM_SURR_MAX_ACTIVE = 5)
     off = 0
     for i, b in enumerate(used):
         active = [d for d in range(D) if b[d] > 0]
         idx[i, 0], idx[i, 1] = len(active), off
         for a, d in enumerate(active):
-            idx[i, 2 + a], idx[i, 5 + a] = d, b[d]
+            idx[i, 2 + a], idx[i, 7 + a] = d, b[d]
         off += values[b].shape[0]
     t = rng.uniform(-1, 1, (D, n))
     t[:, 0] = 0.0
@@ -141,14 +141,14 @@ def test_predict_kernel_synthetic_tables_all_output_widths(n_out):
     d_val, d_t = dev(np.concatenate([values[b] for b in used])), dev(t)
     out = torch.full((n_out, n + 7), np.nan, dtype=torch.float64, device='cuda')
     p = lambda x: C.c_void_p(x.data_ptr())                                               # noqa: E731
-    _lib.check(_lib.load().pem_sparse_predict_f64_dev(n, D, len(used), p(d_idx), p(d_coef), p(d_val), n_out, p(d_t), n, p(out), n + 7,
+    _lib.check(_lib.load().pem_sparse_predict_f64_dev(n, D, len(used), p(d_idx), p(d_coef), p(d_val), n_out, p(d_t), n, p(out), n + 7, 3, 3,
                                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     torch.cuda.synchronize()
     got = out.cpu().numpy()
     assert np.isnan(got[:, n:]).all()                                    # nothing written past the n points of a row
     want = snp.predict(used, coefs, values, t)
     assert np.max(np.abs(got[:, :n] - want) / np.abs(want).max(axis=1, keepdims=True)) < 1e-12
-    assert _lib.load().pem_sparse_predict_f64_dev(n, 33, len(used), p(d_idx), p(d_coef), p(d_val), n_out, p(d_t), n, p(out), n + 7, None) != 0
+    assert _lib.load().pem_sparse_predict_f64_dev(n, 33, len(used), p(d_idx), p(d_coef), p(d_val), n_out, p(d_t), n, p(out), n + 7, 3, 3, None) != 0
 
 
 @pytest.mark.gpu
@@ -170,3 +170,83 @@ def test_grid_values_times_coefficients_is_the_prediction():
     # the constant grid (beta = 0) returns the model value at the centre of the box for every point
     zero = I.index((0,) * len(VARIED))
     assert torch.equal(gv[zero], torch.from_numpy(s.values[(0,) * len(VARIED)][0]).cuda()[:, None].expand(-1, 777))
+
+
+@pytest.mark.gpu
+def test_grids_of_level_four_and_five_active_dimensions_match_numpy():
+    """Round 4: a multi-index may have up to five active dimensions of level four (PEM_SURR_MAX_ACTIVE / _LEVEL; three and three
+    before).  Tables that hold such grids against the numpy restatement, with the LDS the launch takes sized from the table."""
+    import torch
+    from oracle import surrogate_np as snp
+    s = SparseGridSurrogate(VARIED, FIXED)
+    rng = np.random.default_rng(3)
+    want_grids = [(4, 0, 0, 0, 0, 0, 0, 0), (0, 0, 0, 0, 0, 0, 0, 4), (1, 1, 1, 1, 0, 0, 0, 0), (1, 1, 1, 1, 1, 0, 0, 0), (2, 1, 0, 1, 0, 0, 1, 1),
+                  (0, 4, 0, 0, 1, 0, 0, 0), (1, 0, 0, 0, 0, 0, 0, 4), (0, 0, 3, 0, 0, 2, 0, 1), (1, 2, 0, 0, 0, 1, 0, 0)]
+    for beta in want_grids:
+        s._ensure_values(beta)
+    I = sorted(s.values)
+    t = rng.uniform(-1, 1, (len(VARIED), 600))
+    t[:, 0] = 0.0
+    t[0, 1], t[7, 2], t[1, 3] = 1.0, -1.0, -np.cos(np.pi * 5 / 16)           # exact hits of level-4 nodes
+    coefs = {b: float(rng.integers(-2, 3)) or 1.0 for b in I}                  # any coefficients: the formula is linear in them
+    idx, _, vals, nb, na, lv = s._build_tables(I, unit_coefficients=True)
+    assert (na, lv) == (5, 4)
+    gv = s.grid_values(torch.from_numpy(t).cuda(), I).cpu().numpy()            # [B][n_out][n]
+    got = np.tensordot(np.array([coefs[b] for b in I]), gv, axes=1)
+    want = snp.predict(I, coefs, s.values, t)
+    assert np.max(np.abs(got - want) / np.abs(want).max(axis=1, keepdims=True)) < 1e-11
+    # the C entry point refuses what it is not built for
+    import ctypes as C
+    from hallthrusterpem_amd import _lib
+    p = lambda x: C.c_void_p(x.data_ptr())                                                             # noqa: E731
+    td = torch.from_numpy(t).cuda()
+    out = torch.empty((s.n_out, 600), dtype=torch.float64, device='cuda')
+    coef = torch.ones(nb, dtype=torch.float64, device='cuda')
+    assert _lib.load().pem_sparse_predict_f64_dev(600, 8, nb, p(idx), p(coef), p(vals), s.n_out, p(td), 600, p(out), 600, 6, 4, None) == 1
+    assert _lib.load().pem_sparse_predict_f64_dev(600, 8, nb, p(idx), p(coef), p(vals), s.n_out, p(td), 600, p(out), 600, 5, 5, None) == 1
+
+
+@pytest.mark.gpu
+def test_field_surrogate_interpolates_latents_and_reconstructs_the_profile():
+    """qoi with 'j_ion': the surrogate carries the field as the latent coefficients of its SVD map (yml:273-280, gen_data.py:261-294,
+    fit_surr.py:101-133).  The node values are the fused evaluate-and-compress launch's; `predict` equals the numpy restatement on
+    all 3 + r outputs; `predict_fields` -- one launch -- equals predict followed by the reconstruction kernel, and tracks the
+    true model's profile."""
+    import torch
+    from hallthrusterpem_amd.batch import CoupledBatch
+    from oracle import surrogate_np as snp
+    s = SparseGridSurrogate(VARIED, FIXED, qoi=('V_cc', 'div_angle', 'T_c', 'j_ion'), num_compress=500, compress_seed=1)
+    r = s.compression.rank
+    assert s.field == 'j_ion' and 1 <= r <= 13 and s.n_out == 3 + r and s.out_names[:3] == ('V_cc', 'div_angle', 'T_c')
+    assert s.compression.relative_error <= 0.01                                  # reconstruction_tol of the YAML
+    hist = s.refine(max_iter=80, num_refine=500, seed=0)
+    assert len(hist) == 80
+    rng = np.random.default_rng(5)
+    n = 3000
+    t = rng.uniform(-1, 1, (len(VARIED), n))
+    td = torch.from_numpy(t).cuda()
+    pred = s.predict(td)
+    want = snp.predict(s.index_set, s.combination_coefficients(s.index_set), s.values, t[:, ::10])
+    assert np.max(np.abs(pred[:, ::10].cpu().numpy() - want) / np.abs(want).max(axis=1, keepdims=True)) < 1e-12
+    both = s.predict_fields(td)
+    assert set(both) == {'V_cc', 'div_angle', 'T_c', 'j_ion', 'j_ion_latent'} and both['j_ion'].shape == (n, 91)
+    for i, k in enumerate(('V_cc', 'div_angle', 'T_c')):
+        assert torch.equal(both[k], pred[i])
+    assert torch.equal(both['j_ion_latent'], pred[3:].T)
+    rec = s.compression.reconstruct(pred[3:].T.contiguous())                     # pem_svd_reconstruct_f64_dev (fp64 MFMA) on the same latents
+    assert torch.allclose(both['j_ion'], rec, rtol=1e-11, atol=0.0)
+    # against the true model: the profile in its norm (log10), and the latents the true model compresses to
+    x = {k: np.full(n, v) for k, v in FIXED.items()}
+    x.update(s.to_physical(t))
+    b = CoupledBatch(n, profile=True)
+    b.set_inputs(x)
+    b.run()
+    torch.cuda.synchronize()
+    lt, lp = torch.log10(b.j_ion), torch.log10(both['j_ion'])
+    err = float(torch.linalg.norm(lp - lt) / torch.linalg.norm(lt))
+    assert err < 0.03, err                                                       # (80 refinements; configs[3]'s 160 reach 0.008: tests/test_baseline_configs.py)
+    # interpolation property on the latents: at the nodes of an active grid the surrogate returns the compressed true model
+    beta = max(s.index_set, key=lambda b: sum(b))
+    at = s.predict(torch.from_numpy(s._grid(beta)).cuda(), index_set=[b for b in s.index_set]).cpu().numpy().T
+    full_rows = s.values[beta]
+    assert np.max(np.abs(at - full_rows) / (np.abs(full_rows).max(axis=0) + 1e-300)) < 1e-9

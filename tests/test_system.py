@@ -98,7 +98,7 @@ def test_generate_data_and_process_compression_like_gen_data(tmp_path):
 
 
 @pytest.mark.gpu
-def test_fit_trains_a_surrogate_and_predict_switches_to_it():
+def test_fit_trains_a_surrogate_and_predict_switches_to_it(tmp_path):
     from hallthrusterpem_amd.system import PemV0System
     system = PemV0System(seed=2)
     fixed = {k: v for k, v in dict(P_b=1e-5, V_a=300.0, T_e=2.0, Pstar=3e-5, P_T=2e-5, mdot_a=5e-6, a_1=0.01, c0=0.5,
@@ -119,6 +119,19 @@ def test_fit_trains_a_surrogate_and_predict_switches_to_it():
     assert evals.shape == (8,) and evals.sum() == hist[-1]['model_evals'] and overhead == 0.0
     system.clear()
     assert system.surrogate is None and system.train_history == []
+    # round 4: with no targets named the surrogate carries every output -- the scalars and j_ion through its SVD latents
+    # (pem_v0_SPT-100.yml:273-280) -- and predict() returns the reconstructed profile with its coordinates, as the true model does
+    hist = system.fit(fixed=fixed, max_iter=6, max_tol=0.0, num_refine=300, test_set=(xt, yt))
+    assert system.surrogate.field == 'j_ion' and set(hist[-1]['test_error']) == {'V_cc', 'div_angle', 'T_c', 'j_ion'}
+    assert hist[-1]['test_error']['j_ion'] < 0.05
+    pred = system.predict(xt, normalized_inputs=False)
+    assert set(pred) == {'V_cc', 'div_angle', 'T_c', 'j_ion', 'j_ion_coords'} and pred['j_ion'].shape == (2000, 91)
+    assert pred['j_ion_coords'].shape == (2000,) and np.array_equal(pred['j_ion_coords'][7], yt['j_ion_coords'][7])
+    assert np.all(pred['j_ion'] > 0)
+    saved = system.save_to_file('sys.pkl', save_dir=tmp_path)
+    again = PemV0System.load_from_file(saved)
+    p2 = again.predict(xt, normalized_inputs=False)
+    assert np.array_equal(p2['j_ion'], pred['j_ion']) and np.array_equal(p2['T_c'], pred['T_c'])
 
 
 @pytest.mark.gpu
