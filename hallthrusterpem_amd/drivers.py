@@ -500,6 +500,57 @@ def generate_data_on_device(n: int, seed: int = 0, description: str = 'test_set'
     return {description: (samples, outputs), 'nan_idx': nan_idx, 'outlier_idx': outlier_idx, 'iqr_factor': iqr_factor}
 
 
+# ------------------------------------------------------------------------------------------- surrogate training
+def train_surrogate(system, fidelity: str = 'multi', **fit_kwargs):
+    """scripts/fit_surr.py:101-200 on a `system.PemV0System`: train the surrogate with `system.fit(num_refine=1000, ...)`, read the
+    allocation (`get_allocation()`'s 4-tuple, per (component, alpha)) and the test-error history, for the multi-fidelity run, the
+    single-fidelity run (components' `model_fidelity` emptied, `system.clear()` first), or both (the second under
+    `root_dir / 'amisc_single_fidelity'`).  The coupled PEM-v0 graph has ONE fidelity here -- the reference's only multi-fidelity
+    component is the Julia thruster, out of scope -- so the two runs train the same surrogate; the shape of the call and of what
+    comes back is the reference's.  Returns {'multi' | 'single': {'cost_alloc', 'model_cost', 'overhead_cost', 'model_evals',
+    'train_history', 'test_error' ([iterations][targets]), 'highest_cost'}}; plotting is left out (fit_surr.py:162-200)."""
+    import copy
+    if fidelity not in ('multi', 'single', 'both'):
+        raise ValueError("fidelity must be 'multi', 'single' or 'both'")
+    fit_kwargs = dict(dict(num_refine=1000), **fit_kwargs)
+    for k in ('estimate_bounds', 'update_bounds', 'plot_interval'):      # amisc options without a counterpart (accepted, unused)
+        fit_kwargs.pop(k, None)
+    targets = fit_kwargs.get('targets', None)
+    results = {}
+
+    def one_run(tag):
+        system.fit(**fit_kwargs)
+        system.plot_allocation()
+        cost_alloc, model_cost, overhead, evals = system.get_allocation()
+        history = copy.deepcopy(system.train_history)
+        live = evals[np.nonzero(evals)]
+        if getattr(system, 'logger', None) is not None and live.size:
+            system.logger.info(f'Minimum model evaluations per iteration: {np.min(live):.2f}')
+            system.logger.info(f'Average model evaluations per iteration: {np.mean(live):.2f}')
+            system.logger.info(f'Maximum model evaluations per iteration: {np.max(live):.2f}')
+        names = list(targets or (history[-1].get('test_error') or {}).keys())
+        test = np.full((len(history), len(names)), np.nan)
+        for j, res in enumerate(history):
+            for i, var in enumerate(names):
+                if res.get('test_error') is not None and var in res['test_error']:
+                    test[j, i] = res['test_error'][var]
+        # the cost of one evaluation at the highest fidelity, per component, summed (fit_surr.py:134-139)
+        highest = sum(max(system[c.name].model_costs.values()) for c in system.components if c.name in cost_alloc)
+        results[tag] = {'cost_alloc': cost_alloc, 'model_cost': model_cost, 'overhead_cost': overhead, 'model_evals': evals,
+                        'train_history': history, 'test_error': test, 'targets': names, 'highest_cost': highest}
+
+    if fidelity in ('multi', 'both'):
+        one_run('multi')
+    if fidelity in ('single', 'both'):
+        system.clear()
+        for comp in system.components:
+            comp.model_fidelity = ()
+        if fidelity == 'both' and system.root_dir is not None:
+            system.root_dir = system.root_dir / 'amisc_single_fidelity'
+        one_run('single')
+    return results
+
+
 # ------------------------------------------------------------------------------------------- Sobol' indices
 def sobol_indices(n_base: int, seed: int = 0, qois=QOI_NAMES, priors=None, fixed: dict | None = None,
                   batch_size: int = 1 << 20, device=None, group=None, precision: str = 'fp64', fused: bool | None = None):

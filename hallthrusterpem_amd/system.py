@@ -87,8 +87,21 @@ def to_model_dataset(samples: dict, variables):
     return out, {}
 
 
+class Component:
+    """What scripts/fit_surr.py:119-160 touches of an amisc component: `.name`, `.model_fidelity` (settable: the single-fidelity
+    run of `train_surrogate` empties it), `.model_costs` ({alpha: cost of one evaluation at that fidelity}).  The three PEM-v0
+    sub-models are evaluated by ONE coupled launch here, so they share one fidelity -- () -- and the cost unit is one coupled
+    evaluation split evenly; the reference's only multi-fidelity component is the Julia thruster (out of scope)."""
+
+    def __init__(self, name: str, share: float):
+        self.name, self.model_fidelity, self.model_costs = name, (), {'()': float(share)}
+
+    def __str__(self):
+        return self.name
+
+
 class PemV0System:
-    components = ('Cathode', 'Thruster (analytic test double)', 'Plume')
+    COMPONENT_NAMES = ('Cathode', 'Thruster (analytic test double)', 'Plume')
 
     def __init__(self, root_dir=None, name: str = 'PEM_v0_SPT-100', priors=None, seed: int = 0, sweep_radius: float = 1.0):
         self.name, self.root_dir = name, root_dir
@@ -105,6 +118,7 @@ class PemV0System:
         self.surrogate = None
         self.train_history = []
         self.logger = logging.getLogger(name)
+        self.components = [Component(nm, 1.0 / len(self.COMPONENT_NAMES)) for nm in self.COMPONENT_NAMES]
 
     @property
     def root_dir(self):
@@ -119,6 +133,17 @@ class PemV0System:
             self._root_dir.mkdir(parents=True, exist_ok=True)
 
     # ------------------------------------------------------------------------------------------------ bookkeeping
+    def __getitem__(self, name):
+        """system[component name] (fit_surr.py:137: `system[comp.name].model_costs`)"""
+        for c in self.components:
+            if c.name == str(name):
+                return c
+        raise KeyError(name)
+
+    def plot_allocation(self, *_, **__):
+        """fit_surr.py:117 calls it between fit and get_allocation: there is one component-fidelity pair, nothing to draw"""
+        return None
+
     def inputs(self):
         return self._inputs
 
@@ -243,7 +268,10 @@ class PemV0System:
         evals = np.array([h['model_evals'] for h in self.train_history], dtype=np.float64)
         per_iter = np.diff(evals, prepend=0.0)
         total = float(evals[-1]) if evals.size else 0.0
-        return {'PEM-v0': {'()': total}}, {'PEM-v0': {'()': 1.0}}, 0.0, per_iter
+        # per (component, alpha), as amisc keys them; every evaluation of the coupled graph evaluates all three components once
+        cost_alloc = {c.name: {str(c.model_fidelity): total * c.model_costs['()']} for c in self.components}
+        model_cost = {c.name: dict(c.model_costs) for c in self.components}
+        return cost_alloc, model_cost, 0.0, per_iter
 
     # ------------------------------------------------------------------------------------------------ persistence
     def save_to_file(self, filename, save_dir=None):

@@ -128,6 +128,23 @@ def test_fit_trains_a_surrogate_and_predict_switches_to_it(tmp_path):
     assert set(pred) == {'V_cc', 'div_angle', 'T_c', 'j_ion', 'j_ion_coords'} and pred['j_ion'].shape == (2000, 91)
     assert pred['j_ion_coords'].shape == (2000,) and np.array_equal(pred['j_ion_coords'][7], yt['j_ion_coords'][7])
     assert np.all(pred['j_ion'] > 0)
+    # get_allocation is keyed per (component, alpha) as fit_surr.py:119-139 reads it; train_surrogate has the reference's shape
+    cost_alloc, model_cost, overhead, evals = system.get_allocation()
+    assert set(cost_alloc) == {c.name for c in system.components} == set(model_cost) and len(system.components) == 3
+    assert abs(sum(v['()'] for v in cost_alloc.values()) - hist[-1]['model_evals']) < 1e-9
+    assert abs(sum(max(system[c.name].model_costs.values()) for c in system.components) - 1.0) < 1e-12
+    from hallthrusterpem_amd import drivers
+    system.clear()
+    res = drivers.train_surrogate(system, fidelity='both', targets=['V_cc', 'div_angle'], fixed=fixed, max_iter=3, max_tol=0.0,
+                                  num_refine=200, test_set=(xt, yt), estimate_bounds=True, plot_interval=5)
+    assert set(res) == {'multi', 'single'} and res['multi']['test_error'].shape == (3, 2) and res['single']['targets'] == ['V_cc', 'div_angle']
+    assert res['single']['model_evals'].shape == (3,) and abs(res['multi']['highest_cost'] - 1.0) < 1e-12
+    assert np.array_equal(res['multi']['test_error'], res['single']['test_error'])        # one fidelity: the same surrogate twice
+    with pytest.raises(ValueError):
+        drivers.train_surrogate(system, fidelity='low')
+    system.clear()
+    hist = system.fit(fixed=fixed, max_iter=6, max_tol=0.0, num_refine=300, test_set=(xt, yt))
+    pred = system.predict(xt, normalized_inputs=False)
     saved = system.save_to_file('sys.pkl', save_dir=tmp_path)
     again = PemV0System.load_from_file(saved)
     p2 = again.predict(xt, normalized_inputs=False)
