@@ -75,7 +75,7 @@ __device__ __forceinline__ int bin_of_d(u64 k, u64 lo, double inv, int bins) {
 
 struct Column {          // per column
     u64 kmin, kmax;
-    int has_nan, pad;
+    int has_nan, pad;    // has_nan: the number of NaNs the min / max pass met (the pilot form's counting pass only flags: 1)
     unsigned mult;       // floor(2^32 BINS1 / (((kmax - kmin) >> shift) + 1))
     int shift;           // so that (kmax - kmin) >> shift < 2^31
 };
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(QBLOCK) void minmax_kernel(long long n, int m, size
         nan[j] = 0;
     }
     stream_values<NC>(n, m, ld, data, L, [&](int j, int, double x) {
-        if (x != x) nan[j] = 1;
+        if (x != x) nan[j] += 1;                   // (counted: the histogram's total is checked against n - NaNs, decide1_kernel)
         else {
             const u64 k = key_of(x);
             lo[j] = k < lo[j] ? k : lo[j];
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(QBLOCK) void minmax_kernel(long long n, int m, size
                 atomicMin(&s_lo[c], lo[j]);
                 atomicMax(&s_hi[c], hi[j]);
             }
-            if (nan[j]) atomicOr(&s_nan[c], 1);
+            if (nan[j]) atomicAdd(&s_nan[c], nan[j]);
         }
     }
     __syncthreads();
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(QBLOCK) void minmax_kernel(long long n, int m, size
             atomicMin(&col[c].kmin, s_lo[c]);
             atomicMax(&col[c].kmax, s_hi[c]);
         }
-        if (s_nan[c]) atomicOr(&col[c].has_nan, 1);
+        if (s_nan[c]) atomicAdd(&col[c].has_nan, s_nan[c]);
     }
 }
 
@@ -295,10 +295,19 @@ __device__ __forceinline__ Found find_bin(const unsigned* __restrict__ h, int bi
 }
 
 // one wave per (column, target): the bin that holds the rank
+// (and an invariant while the histogram is at hand -- ADVICE r3: an LDS atomic lost in the counting pass would shift a rank silently,
+// both later passes agreeing on the wrong count: the column's bins must add up to its rows minus its NaNs, or the call fails)
 __global__ __launch_bounds__(64) void decide1_kernel(int m, int nt, const Column* __restrict__ col, const unsigned* __restrict__ hist1, int bins1,
-                                                      Target* __restrict__ tg) {
+                                                      Target* __restrict__ tg, long long rows, int* __restrict__ inconsistent) {
     const int i = blockIdx.x, lane = threadIdx.x;
     const int c = i / nt;
+    if (i == c * nt) {
+        u64 sum = 0;
+        for (int b = lane; b < bins1; b += 64) sum += hist1[(size_t)c * bins1 + b];
+#pragma unroll
+        for (int sh = 32; sh >= 1; sh >>= 1) sum += __shfl_xor(sum, sh);
+        if (lane == 0 && sum != (u64)(rows - col[c].has_nan)) atomicExch(inconsistent, 1 + c);
+    }
     Target t = tg[i];
     t.owner = i - c * nt;
     if (col[c].kmin >= col[c].kmax) {          // a constant column (or one without a finite value: its result is NaN anyway)
@@ -929,6 +938,23 @@ __global__ void premask_bounds_kernel(int m, int nq, const Bracket* __restrict__
     thr[c] = make_uint4(key_high(lo_min), key_high(lo_max), key_high(hi_min), key_high(hi_max));
 }
 
+// the records the producer wrote are the values the record histogram counted (one workgroup)
+__global__ __launch_bounds__(QBLOCK) void record_total_check_kernel(const unsigned* __restrict__ rec_count, unsigned cap, unsigned waves,
+                                                                     const unsigned* __restrict__ hist, int cells, int* __restrict__ inconsistent,
+                                                                     const int* __restrict__ prod_flags) {
+    __shared__ u64 s_rec, s_hist;
+    if (threadIdx.x == 0) s_rec = s_hist = 0;
+    __syncthreads();
+    u64 r = 0, h = 0;
+    for (unsigned w = threadIdx.x; w < waves; w += QBLOCK) r += rec_count[w] < cap ? rec_count[w] : cap;
+    for (int i = threadIdx.x; i < cells; i += QBLOCK) h += hist[i];
+    atomicAdd(&s_rec, r);
+    atomicAdd(&s_hist, h);
+    __syncthreads();
+    // (a run the producer flagged -- overflow, a non-finite value -- is discarded anyway, and its records need not add up)
+    if (threadIdx.x == 0 && s_rec != s_hist && !prod_flags[0] && !prod_flags[1]) atomicExch(inconsistent, -1);
+}
+
 constexpr int REC_LISTS_MAX = 64 * 2 * PEM_QUANTILE_MAX_Q;     // (column, quantile) pairs the record kernels keep a table of (m <= 128)
 
 // the list (column * nq + quantile) of a record: the bracket of its column whose high words hold the key's (they do not overlap)
@@ -1120,7 +1146,7 @@ __global__ void export_minmax_kernel(const Column* __restrict__ col, int m, u64*
     if (c < m) {
         kmin[c] = col[c].kmin;
         kmax[c] = col[c].kmax;
-        has_nan[c] = col[c].has_nan;
+        has_nan[c] = col[c].has_nan ? 1 : 0;
     }
 }
 
@@ -1231,6 +1257,7 @@ static int quantiles_impl(size_t n, int m, const double* data, size_t ld, size_t
     unsigned* rec_count = reinterpret_cast<unsigned*>(ws + o_rc);
     uint4* pm_thr = reinterpret_cast<uint4*>(ws + o_pm);
     int* pm_bad = unfit + 3;                                               // fused form: premask bounds unfit
+    int* inconsistent = unfit + 4;                                         // a histogram's total is not the number of values counted (1 + column)
     Bracket* br = reinterpret_cast<Bracket*>(ws + o_br);
     u64* below = reinterpret_cast<u64*>(ws + o_bl);
     unsigned* histA = reinterpret_cast<unsigned*>(ws + o_hA);
@@ -1326,7 +1353,7 @@ static int quantiles_impl(size_t n, int m, const double* data, size_t ld, size_t
     Q_LDS(hist1_kernel<NC_>);                                                                              \
     hipLaunchKernelGGL(hist1_kernel<NC_>, grid, blk, lds1, st, (long long)rows, m, ldd, cs, data, col, bins1, hist1)
         Q_BY_NC(Q_HIST1);
-        hipLaunchKernelGGL(decide1_kernel, dim3((unsigned)(m * nt)), dim3(64), 0, st, m, nt, col, hist1, bins1, tg);
+        hipLaunchKernelGGL(decide1_kernel, dim3((unsigned)(m * nt)), dim3(64), 0, st, m, nt, col, hist1, bins1, tg, (long long)rows, inconsistent);
 #define Q_HIST2_(NC_, NT_)                                                                                                  \
     Q_LDS((hist2_kernel<NC_, NT_>));                                                                                        \
     hipLaunchKernelGGL((hist2_kernel<NC_, NT_>), grid, blk, lds2, st, (long long)rows, m, ldd, cs, data, col, tg, bins1, bins2, hist2)
@@ -1448,6 +1475,7 @@ static int quantiles_impl(size_t n, int m, const double* data, size_t ld, size_t
                 default: Q_RECHIST(6); break;
             }
 #undef Q_RECHIST
+            hipLaunchKernelGGL(record_total_check_kernel, dim3(1), blk, 0, st, rec_count, rcap, fused_waves, histA, m * nq * binsA, inconsistent, prod_flags);
         }
         hipLaunchKernelGGL(decide_bracket_kernel, dim3((unsigned)(m * nt)), dim3(64), 0, st, nt, col, br, below, histA, binsA, tg, outside);
         hipLaunchKernelGGL(layout_kernel, dim3(1), dim3(64 * MAX_NC), 0, st, m, nt, tg, total);
@@ -1498,8 +1526,15 @@ static int quantiles_impl(size_t n, int m, const double* data, size_t ld, size_t
     hipLaunchKernelGGL(finish_kernel, dim3((unsigned)((m * nq + 63) / 64)), dim3(64), 0, st, m, nq, col, tg, w, out);
     Q_TRY(hipGetLastError());
     u64 h_incomplete[4] = {0, 0, 0, 0};
+    int h_inconsistent = 0;
     Q_TRY(hipMemcpyAsync(h_incomplete, incomplete, sizeof h_incomplete, hipMemcpyDeviceToHost, st));
+    Q_TRY(hipMemcpyAsync(&h_inconsistent, inconsistent, sizeof(int), hipMemcpyDeviceToHost, st));
     Q_TRY(hipStreamSynchronize(st));
+    if (h_inconsistent > 0)
+        return pem::fail(PEM_ERR_HIP, "pem_quantiles: the histogram of column %d does not add up to its number of values (internal error; result discarded; path %d)",
+                         h_inconsistent - 1, path);
+    if (h_inconsistent < 0)
+        return pem::fail(PEM_ERR_HIP, "pem_quantiles: the record histogram does not add up to the number of records (internal error; result discarded)");
     if ((h_incomplete[0] & 0xffffffffull) && h_incomplete[2] == h_incomplete[3])
         return pem::fail(PEM_ERR_HIP, "pem_quantiles: a candidate list was sorted with fewer keys than it holds (internal error; result discarded; path %d)", path);
     if (h_incomplete[0] & 0xffffffffull)
