@@ -1156,6 +1156,7 @@ __device__ __forceinline__ void stream_run(const double* from, double* dst, int 
 
 constexpr int RADII_SMALL = 8;                  // up to here: the recurrence kernel with the radii in registers (plume_rfew_kernel)
 constexpr int RMID_MAX = 64;
+constexpr int RMID_G_MAX = 5;                   // samples in flight per wave the staged kernel is instantiated for (R >= 11)
 constexpr int RMID_TILE = 1024;                 // doubles of staged rows per wave
 struct RadiiMidArg {
     double r[RMID_MAX];
@@ -1193,12 +1194,12 @@ void plume_rmid_kernel(PlumeIO io, RadiiMidArg radii_arg, int R, int ts) {
         const long long gl = (lane < ts && t * ts + lane < io.n) ? t * ts + lane : io.n - 1;
         const double c0_l = io.c0[gl], c1_l = io.c1[gl];
         const PlumeSetup ps_l = plume_setup(io.P_b[gl], c1_l, io.c2[gl], io.c3[gl], io.c4[gl], io.c5[gl], io.torr2pa);
-        const double nn_l = ps_l.n_neutral, sigma_l = io.sigma[gl];
-        const double IB0_l = io.I_B0[gl];
+        // (sigma, I_B0 and T of a sample are read again by its own lanes when its group comes up -- three loads that hit the cache --
+        // instead of being carried in registers across the tile: with them the kernel was eight registers over three waves per SIMD)
+        const double nn_l = ps_l.n_neutral;
         const double a1_l = ps_l.a1, a2_l = ps_l.a2;
         const double A1_l = (1.0 - c0_l) / normaliser(a1_l, 1.0 / (a1_l * a1_l), PEM_DPOLY);
         const double A2_l = c0_l / normaliser(a2_l, 1.0 / (a2_l * a2_l), PEM_DPOLY);
-        const double thrust_l = have_T ? io.T[gl] : 0.0;
         const int in_tile = (int)(io.n - t * ts < ts ? io.n - t * ts : ts);
         for (int s0 = 0; s0 < in_tile; s0 += G) {
             // The Gaussians of the group's samples: the LS lanes of a sample take CHK consecutive angles each and advance
@@ -1218,11 +1219,11 @@ void plume_rmid_kernel(PlumeIO io, RadiiMidArg radii_arg, int R, int ts) {
                 double e1 = exp_nonpos(-(double)(k0 * k0) * s1), r1 = exp_nonpos(-(double)(2 * k0 + 1) * s1);
                 double e2 = exp_nonpos(-(double)(k0 * k0) * s2), r2 = exp_nonpos(-(double)(2 * k0 + 1) * s2);
                 const double q1 = exp_nonpos(-2.0 * s1), q2 = exp_nonpos(-2.0 * s2);
-                double2 ev[CHK_MAX];
+                // (straight into LDS: kept in a register array first -- up to 11 pairs at 9 radii -- the kernel spilled 14-36 registers)
                 double lo = __builtin_inf();
 #pragma unroll
                 for (int i = 0; i < CHK_MAX; ++i) {
-                    ev[i] = make_double2(e1, e2);
+                    if (i < chk && lane_on && k0 + i < NANG) E[grp * RMID_ES + k0 + i] = make_double2(e1, e2);
                     if (i < chk) lo = fmin(lo, fmin(e1, e2));
                     e1 *= r1;
                     r1 *= q1;
@@ -1230,25 +1231,21 @@ void plume_rmid_kernel(PlumeIO io, RadiiMidArg radii_arg, int R, int ts) {
                     r2 *= q2;
                 }
                 if (!(lo >= 1e-290) || !__builtin_isfinite(s1) || !__builtin_isfinite(s2)) {
-#pragma unroll
-                    for (int i = 0; i < CHK_MAX; ++i) {
+                    for (int i = 0; i < chk; ++i) {
                         const int k = k0 + i;
                         const double alpha = k >= NANG - 1 ? HALF_PI : (double)k * GRID_H;
                         const double t1 = alpha / a1g, t2 = alpha / a2g;
-                        if (i < chk) ev[i] = make_double2(exp(-(t1 * t1)), exp(-(t2 * t2)));
+                        if (lane_on && k < NANG) E[grp * RMID_ES + k] = make_double2(exp(-(t1 * t1)), exp(-(t2 * t2)));
                     }
                 }
-#pragma unroll
-                for (int i = 0; i < CHK_MAX; ++i)
-                    if (i < chk && lane_on && k0 + i < NANG) E[grp * RMID_ES + k0 + i] = ev[i];
             }
             // this lane's (sample, radius): amplitudes of plume.py:95-100
             const bool smp_on = s0 + grp < in_tile;
             const int src = smp_on ? s0 + grp : in_tile - 1;          // an idle group repeats the last sample and stores nothing
             const long long g = t * ts + src;
             const double a1 = __shfl(a1_l, src), A1 = __shfl(A1_l, src), A2 = __shfl(A2_l, src);
-            const double n_neutral = __shfl(nn_l, src), sigma = __shfl(sigma_l, src);
-            const double I_B0 = __shfl(IB0_l, src), thrust = __shfl(thrust_l, src);
+            const double n_neutral = __shfl(nn_l, src), sigma = io.sigma[g];
+            const double I_B0 = io.I_B0[g], thrust = have_T ? io.T[g] : 0.0;
             const double decay = exp(-rad * n_neutral * sigma);
             const double j_cex = I_B0 * (1.0 - decay) / (2.0 * PEM_PI * (rad * rad));
             const double base = I_B0 * decay / (rad * rad);
@@ -2135,11 +2132,13 @@ int pem_plume_f64_dev(size_t n, int n_radii, const double* radii, double torr2pa
         return PEM_OK;
     }
     static const bool use_rmid = getenv("PEM_RADII_MID") ? atoi(getenv("PEM_RADII_MID")) != 0 : true;
-    static const int rmid_min = getenv("PEM_RMID_MIN") ? atoi(getenv("PEM_RMID_MIN")) : 17;
+    // (read per call: tests walk through the instantiations; at most five samples per wave -- 11 radii or more -- are built)
+    int rmid_min = getenv("PEM_RMID_MIN") ? atoi(getenv("PEM_RMID_MIN")) : 17;
+    if (rmid_min < WAVE / RMID_G_MAX + 1) rmid_min = WAVE / RMID_G_MAX + 1;
     if (use_rmid && n_radii >= rmid_min && n_radii > RADII_SMALL && n_radii <= RMID_MAX) {
         // 64 / R samples in flight per wave, rows staged in LDS, line-aligned 16-byte stores (plume_rmid_kernel): 3.5-5.2 TB/s
         // of output for 17..64 radii against 3.3-4.9 for the wave-per-sample kernel below (25 radii: 3.8-4.0 against 3.2-3.35).
-        // From 9 radii on (PEM_RMID_MIN=9) it works but gains nothing over the kernel below (2.9 / 3.3 / 3.9 against 2.9 / 3.1 /
+        // From 11 radii on (PEM_RMID_MIN=11) it works but gains nothing over the kernel below (2.9 / 3.3 / 3.9 against 2.9 / 3.1 /
         // 4.1 TB/s at 9 / 12 / 16 radii): seven samples share the 8 KB of staged rows, and their 1.1 KB runs pay the run's head /
         // body / tail code 42 times per group (profiles/radii_mid_r03.txt)
         RadiiMidArg ra;
@@ -2169,9 +2168,7 @@ int pem_plume_f64_dev(size_t n, int n_radii, const double* radii, double torr2pa
             case 2: PEM_RMID_LAUNCH(2); break;
             case 3: PEM_RMID_LAUNCH(3); break;
             case 4: PEM_RMID_LAUNCH(4); break;
-            case 5: PEM_RMID_LAUNCH(5); break;
-            case 6: PEM_RMID_LAUNCH(6); break;
-            default: PEM_RMID_LAUNCH(7); break;
+            default: PEM_RMID_LAUNCH(5); break;          // (64 / R <= RMID_G_MAX: checked above)
         }
 #undef PEM_RMID_LAUNCH
         HIP_TRY(hipGetLastError());

@@ -544,3 +544,27 @@ def test_sweep_radius_counts_across_the_kernel_switches(pem, oc, R):
     assert rel_err(out['j_ion'], ref['j_ion']) <= RTOL
     assert div_err(out['div_angle'], ref['div_angle']) <= RTOL and rel_err(out['T_c'], ref['T_c']) <= RTOL
     assert ref['invalid'].any() and np.array_equal(np.all(out['j_ion'].reshape(n, -1) == 1e-20, axis=1), ref['invalid'])
+
+
+@pytest.mark.parametrize('R,ts,rmid_min', [(17, 63, None), (17, 32, None), (25, 64, None), (25, 32, None), (33, 64, None), (33, 63, None),
+                                           (11, 60, 11), (12, 64, 11), (13, 32, 11), (16, 64, 11)])
+def test_staged_radii_kernel_at_production_tile_sizes(pem, oc, monkeypatch, R, ts, rmid_min):
+    """plume_rmid_kernel (17..64 sweep radii by default) as large batches run it -- the host picks tiles of 8 samples for every
+    n < 131072, so the cases above it never saw tiles of 16 / 32 / 64 (63 at three samples per wave), several groups per tile, or
+    shuffles from lanes >= 8 -- and the instantiations for four and five samples per wave, reachable through
+    PEM_RMID_MIN only (11..16 radii; six and seven were dropped).  Against the oracle, invalid samples and a ragged tile included."""
+    from hallthrusterpem_amd.models import current_density
+    monkeypatch.setenv('PEM_RMID_TS', str(ts))
+    if rmid_min is not None:
+        monkeypatch.setenv('PEM_RMID_MIN', str(rmid_min))
+    n = 1000 + R
+    x = plume_inputs(n, seed=90 + R + ts, priors=False)
+    x['c3'][:7], x['c2'][:7] = -0.1, 0.0
+    x['c0'][7:11] = 1.3
+    x['c3'][-1], x['c2'][-1] = -0.2, 0.0                      # an invalid sample in the ragged last tile
+    radii = np.linspace(0.4, 2.0, R)
+    out = current_density(x, sweep_radius=radii)
+    ref = oc.plume(*[x[k] for k in PLUME_KEYS], pem.constants.TORR_2_PA, T=x['T'], radii=radii)
+    assert rel_err(out['j_ion'], ref['j_ion']) <= RTOL
+    assert div_err(out['div_angle'], ref['div_angle']) <= RTOL and rel_err(out['T_c'], ref['T_c']) <= RTOL
+    assert ref['invalid'].any() and np.array_equal(np.all(out['j_ion'].reshape(n, -1) == 1e-20, axis=1), ref['invalid'])
