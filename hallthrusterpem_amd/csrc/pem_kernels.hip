@@ -307,14 +307,24 @@ __device__ __attribute__((noinline)) ChunkSums exact_chunk(double X1a, double X2
 // and in per-workgroup LDS counters between rounds.  The few per cent of values inside a bracket are noted as one bit per (slot,
 // sample) and leave as 16-byte records {key, angle * nq + quantile}, appended to the wave's own region of the record buffer
 // (no atomics: the count lives in a scalar register) by however many lanes have one left, until none has.
-// Out of line, with its LDS operands as byte offsets into the workgroup's dynamic LDS: inlined into the rounds it cost the kernel
-// 140 registers (one wave per SIMD), and generic pointers would turn its LDS traffic into flat accesses.
-struct QCount {
+// Its LDS operands are byte offsets into the workgroup's dynamic LDS (as an out-of-line function it must not take generic pointers:
+// they would turn its LDS traffic into flat accesses).
+// What count_round needs and the rounds do not: kept in the wave's own LDS words (a record of 48 bytes written once per launch),
+// so that the call carries four arguments and nothing of this stays live in the caller's registers across the rounds (as
+// arguments they cost the counting kernels 8-56 bytes of stack for registers saved around the call).
+struct CountCtx {
+    pem::Record* rec;            // this wave's region of the record buffer
+    uint8_t* row_certain;        // the premask's per-sample counts (whole arrays), or nullptr
+    uint8_t* row_uncertain;
+    unsigned cap;                // records the region holds
     unsigned tab_off;            // LDS [91][NQ] {loh, words}
     unsigned below_off;          // LDS [NQ][91]
-    pem::Record* rec;            // this wave's region
-    unsigned cap, cnt;           // its size; records produced so far (wave-uniform)
     unsigned pm_off;             // LDS [91] uint4: the premask's thresholds
+};
+struct QCount {
+    unsigned ctx_off;            // LDS: this wave's CountCtx
+    unsigned below_off;          // LDS [NQ][91] (the kernel's final flush)
+    unsigned cap, cnt;           // region size; records produced so far (wave-uniform)
 };
 struct NoCount {};
 
@@ -325,18 +335,33 @@ struct NoCount {};
 // hi_max), INSIDE FOR CERTAIN, or uncertain (in one of the two intervals: about one value in a hundred).  Per sample the two
 // counts leave as bytes; the caller settles the few samples whose verdict the uncertain values could change.  Four comparisons of
 // high words per value, kept as wave masks; a row's counts are population counts of those masks.
+// Inlined into the (rolled) rounds.  Its first version, inlined with every loop unrolled, cost the kernel 140 registers and one wave
+// per SIMD, so it went out of line -- where the premask variant saved two callee-saved registers on the stack per call (8 bytes
+// of scratch).  With the sample loops rolled in groups of four the inlined form fits two waves per SIMD (209-228 registers, no
+// scratch) and measures the same (5.13-5.21 against 5.18-5.22 ms per 1e7-sample campaign): -DPEM_COUNT_INLINE=0 is the other form.
+#ifndef PEM_COUNT_INLINE
+#define PEM_COUNT_INLINE 1
+#endif
+#if PEM_COUNT_INLINE
+#define PEM_COUNT_LINKAGE __forceinline__
+#else
+#define PEM_COUNT_LINKAGE __attribute__((noinline))
+#endif
 template <int NQ, int S, bool FULL, bool PM>
-__device__ __attribute__((noinline)) unsigned count_round(unsigned tab_off, unsigned below_off, unsigned tile_off, pem::Record* rec,
-                                                          unsigned cap, unsigned cnt, int lane, int rows, unsigned pm_off,
-                                                          uint8_t* row_certain, uint8_t* row_uncertain) {
+__device__ PEM_COUNT_LINKAGE unsigned count_round(unsigned ctx_off, unsigned tile_off, unsigned cnt, int lane, int rows, long long first) {
 #if defined(PEM_COUNT_EXP) && PEM_COUNT_EXP == 1
     return cnt;
 #endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const uint2* tab = reinterpret_cast<const uint2*>(smem_raw + tab_off);
-    unsigned* below = reinterpret_cast<unsigned*>(smem_raw + below_off);
+    const CountCtx ctx = *reinterpret_cast<const CountCtx*>(smem_raw + ctx_off);
+    const uint2* tab = reinterpret_cast<const uint2*>(smem_raw + ctx.tab_off);
+    unsigned* below = reinterpret_cast<unsigned*>(smem_raw + ctx.below_off);
     const double* tile = reinterpret_cast<const double*>(smem_raw + tile_off);
-    const uint4* pm = reinterpret_cast<const uint4*>(smem_raw + pm_off);   // [91] {certainly below, possibly below, possibly above, certainly above}
+    const uint4* pm = reinterpret_cast<const uint4*>(smem_raw + ctx.pm_off);   // [91] {certainly below, possibly below, possibly above, certainly above}
+    pem::Record* rec = ctx.rec;
+    const unsigned cap = ctx.cap;
+    uint8_t* row_certain = PM ? ctx.row_certain + first : nullptr;
+    uint8_t* row_uncertain = PM ? ctx.row_uncertain + first : nullptr;
     unsigned bits = 0;           // bit 16 slot + s: value s of the slot's angle lies inside a bracket
     unsigned row_c = 0, row_u = 0;   // lane s: values of row s outside for certain / uncertain
     static_assert(S <= 16, "one bit per sample and slot");
@@ -565,11 +590,14 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
         // ------------------------------ ROUNDS: L lanes per sample ------------------------------
         // (the counting modes keep the rounds rolled: unrolled four times with count_round inside, the kernel took 340 registers
         // and one wave per SIMD)
+        // (the reduced-QoI mode takes this loop for the tiles that hold a sample the tables do not cover -- none under the priors:
+        // rolled, with a rolled angle loop, it fits the three waves per SIMD that mode is compiled for; unrolled it spilled there)
 #if defined(PEM_COUNT_EXP) && PEM_COUNT_EXP == 3
         constexpr int ROUND_UNROLL = L;
 #else
-        constexpr int ROUND_UNROLL = NQ > 0 ? 1 : L;
+        constexpr int ROUND_UNROLL = (NQ > 0 || JMODE == 0) ? 1 : L;
 #endif
+        constexpr int ANGLE_UNROLL = JMODE == 0 ? 1 : CH;
 #pragma unroll ROUND_UNROLL
         for (int round = 0; round < L; ++round) {
             const int smp = round * S + s;
@@ -600,10 +628,15 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
             double2 wq[CH];
 #pragma unroll
             for (int j = 0; WRITE_J && j < PF && j < CH; ++j) wq[j] = my_w[j];
-#pragma unroll
+#pragma unroll ANGLE_UNROLL
             for (int j = 0; j < CH; ++j) {
-                if constexpr (!WRITE_J) wq[j] = my_w[j];   // no tile stores in between: the compiler schedules the reads
-                else if (j + PF < CH) wq[j + PF] = my_w[j + PF];
+                double2 wj;
+                if constexpr (!WRITE_J) {
+                    wj = my_w[j];                          // no tile stores in between: the compiler schedules the reads
+                } else {
+                    if (j + PF < CH) wq[j + PF] = my_w[j + PF];
+                    wj = wq[j];
+                }
                 const double f = X1 + X2;     // j_beam + j_scat
                 const double ji = f + jcex;   // plume.py:102
                 if ((L - 1) * CH + j < NANG) {  // an angle every chunk has (compile-time after unrolling)
@@ -614,8 +647,8 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
                     if constexpr (WRITE_J) tile[in_range ? s * NANG + k0 + j : TILE] = (JT)ji;
                     lo = fmin(lo, in_range ? (WRITE_J ? ji : f) : __builtin_inf());
                 }
-                den = fma(wq[j].x, f, den);
-                num = fma(wq[j].y, f, num);
+                den = fma(wj.x, f, den);
+                num = fma(wj.y, f, num);
                 X1 *= rr1;
                 rr1 *= q1;
                 X2 *= rr2;
@@ -692,9 +725,8 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
                 }
                 if constexpr (JMODE == 5) {             // counted, never stored
                     const long long left = io.n - first;
-                    qc.cnt = count_round<NQ, S, FULL, PM>(qc.tab_off, qc.below_off, m.tile_off, qc.rec, qc.cap, qc.cnt, lane,
-                                                          FULL ? S : (int)(left < S ? (left < 0 ? 0 : left) : S), qc.pm_off,
-                                                          PM ? io.q.row_certain + first : nullptr, PM ? io.q.row_uncertain + first : nullptr);
+                    qc.cnt = count_round<NQ, S, FULL, PM>(qc.ctx_off, m.tile_off, qc.cnt, lane,
+                                                          FULL ? S : (int)(left < S ? (left < 0 ? 0 : left) : S), first);
                     wave_lds_sync();
                     continue;
                 }
@@ -723,9 +755,8 @@ __device__ __forceinline__ void process_tile(const PlumeIO& io, const CoupledIO&
                 }
                 if constexpr (JMODE == 4) {             // the stores are on their way (their LDS reads are done): count the tile
                     const long long left = io.n - first;
-                    qc.cnt = count_round<NQ, S, FULL, PM>(qc.tab_off, qc.below_off, m.tile_off, qc.rec, qc.cap, qc.cnt, lane,
-                                                          FULL ? S : (int)(left < S ? (left < 0 ? 0 : left) : S), qc.pm_off,
-                                                          PM ? io.q.row_certain + first : nullptr, PM ? io.q.row_uncertain + first : nullptr);
+                    qc.cnt = count_round<NQ, S, FULL, PM>(qc.ctx_off, m.tile_off, qc.cnt, lane,
+                                                          FULL ? S : (int)(left < S ? (left < 0 ? 0 : left) : S), first);
                 }
                 wave_lds_sync();
             }
@@ -784,7 +815,7 @@ using DesignArg = typename std::conditional<MC, McDesign, NoDesign>::type;
 
 // bytes of LDS the counting modes add per workgroup: brackets' {loh, words} [91][NQ] | below counters [NQ][91] | premask thresholds [91] x 16
 template <int NQ, bool PM>
-constexpr int count_lds_bytes() { return NANG * NQ * 8 + NQ * NANG * 4 + (PM ? NANG * 16 + 8 : 0); }
+constexpr int count_lds_bytes() { return NANG * NQ * 8 + NQ * NANG * 4 + 8 + (PM ? NANG * 16 + 8 : 0) + WPB * (int)sizeof(CountCtx); }
 
 template <int L, bool COUPLED, int JMODE, bool MC = false, int NQ = 0, bool PM = false>
 __global__ __launch_bounds__(WAVE * WPB) __attribute__((amdgpu_waves_per_eu(min_waves_per_simd<JMODE, MC>())))
@@ -848,18 +879,29 @@ void plume_r1_kernel(PlumeIO io, CoupledIO cio, long long ntiles, DesignArg<MC> 
             qbelow[i] = 0;
         }
         const unsigned gw = blockIdx.x * WPB + wave;
-        qc.tab_off = (unsigned)(reinterpret_cast<unsigned char*>(qtab) - smem_raw);
+        unsigned char* after = reinterpret_cast<unsigned char*>(qbelow + NQ * NANG);
+        after = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(after) + 15) & ~uintptr_t(15));
+        unsigned pm_off = 0;
+        if constexpr (PM) {
+            uint4* pmt = reinterpret_cast<uint4*>(after);
+            for (int i = tid; i < NANG; i += WAVE * WPB) pmt[i] = io.q.premask[i];
+            pm_off = (unsigned)(after - smem_raw);
+            after += NANG * sizeof(uint4);
+        }
+        CountCtx* ctx = reinterpret_cast<CountCtx*>(after) + wave;
+        if (lane == 0) {
+            ctx->rec = io.q.rec + (size_t)gw * io.q.cap;
+            ctx->row_certain = io.q.row_certain;
+            ctx->row_uncertain = io.q.row_uncertain;
+            ctx->cap = io.q.cap;
+            ctx->tab_off = (unsigned)(reinterpret_cast<unsigned char*>(qtab) - smem_raw);
+            ctx->below_off = (unsigned)(reinterpret_cast<unsigned char*>(qbelow) - smem_raw);
+            ctx->pm_off = pm_off;
+        }
+        qc.ctx_off = (unsigned)(reinterpret_cast<unsigned char*>(ctx) - smem_raw);
         qc.below_off = (unsigned)(reinterpret_cast<unsigned char*>(qbelow) - smem_raw);
-        qc.rec = io.q.rec + (size_t)gw * io.q.cap;
         qc.cap = io.q.cap;
         qc.cnt = 0;
-        qc.pm_off = 0;
-        if constexpr (PM) {
-            // (16-byte aligned: the tables before it are a whole number of 8-byte words)
-            uint4* pmt = reinterpret_cast<uint4*>((reinterpret_cast<uintptr_t>(qbelow + NQ * NANG) + 15) & ~uintptr_t(15));
-            for (int i = tid; i < NANG; i += WAVE * WPB) pmt[i] = io.q.premask[i];
-            qc.pm_off = (unsigned)(reinterpret_cast<unsigned char*>(pmt) - smem_raw);
-        }
     }
     for (int i = tid; i < NSIMP; i += WAVE * WPB)
         tab_simpson[i] = i < NANG ? make_double2(PEM_SIMPSON_CDEN[i], PEM_SIMPSON_CNUM[i]) : make_double2(0.0, 0.0);

@@ -56,24 +56,24 @@ constexpr int LAT_UNROLL = PEM_LAT_UNROLL;
 constexpr int OUT_STRIDE = 65;     // doubles per column of a wave's output staging block (odd: the transposed reads spread over the banks)
 typedef double lat_f64x2 __attribute__((ext_vector_type(2)));
 
-struct Literal {
-    double den, num, lo;
-    double lat[PEM_FUSED_LATENT_MAX_RANK];
-};
-
 // The slow, literal evaluation of one sample (see exact_chunk / exact_latents in pem_kernels.hip): chunk-wise partial
 // Simpson sums added in chunk order, like the fast loop.  Out of line: it must not cost the fast loop registers.
+// (round 4: inlined at its one call site and writing straight into the caller's accumulators.  Out of line it handed its 3 + RANK
+// results back through a struct on the stack -- 96 bytes of scratch per lane in every instantiation, for a path the priors never
+// take; inlined it reuses the fast loop's registers, which are dead by then.)
 template <int RANK, bool LOGN>
-__device__ __attribute__((noinline)) void literal_sample(double X1a, double X2a, double jcex, double a1, double a2,
-                                                         const double* __restrict__ basis, Literal* out) {
+__device__ __forceinline__ void literal_sample(double X1a, double X2a, double jcex, double a1, double a2,
+                                               const double* __restrict__ basis, double& den, double& num, double& lo, double (&lat)[RANK]) {
 #pragma clang fp contract(off)
-    Literal r;
-    r.den = 0.0;
-    r.num = 0.0;
-    r.lo = __builtin_inf();
-    for (int q = 0; q < RANK; ++q) r.lat[q] = 0.0;
+    den = 0.0;
+    num = 0.0;
+    lo = __builtin_inf();
+#pragma unroll
+    for (int q = 0; q < RANK; ++q) lat[q] = 0.0;
+#pragma unroll 1
     for (int c = 0; c < 4; ++c) {
         double dc = 0.0, nc = 0.0;
+#pragma unroll 1
         for (int j = 0; j < CHUNK; ++j) {
             const int k = c * CHUNK + j;
             if (k >= NANG) break;
@@ -81,16 +81,16 @@ __device__ __attribute__((noinline)) void literal_sample(double X1a, double X2a,
             const double t1 = alpha / a1, t2 = alpha / a2;
             const double f = X1a * exp(-(t1 * t1)) + X2a * exp(-(t2 * t2));
             const double ji = f + jcex;
-            r.lo = fmin(r.lo, f);
+            lo = fmin(lo, f);
             dc = __builtin_fma(PEM_SIMPSON_CDEN[k], f, dc);
             nc = __builtin_fma(PEM_SIMPSON_CNUM[k], f, nc);
             const double lj = LOGN ? pem::pem_log10(ji) : ji;
-            for (int q = 0; q < RANK; ++q) r.lat[q] = __builtin_fma(lj, basis[k * RANK + q], r.lat[q]);
+#pragma unroll
+            for (int q = 0; q < RANK; ++q) lat[q] = __builtin_fma(lj, basis[k * RANK + q], lat[q]);
         }
-        r.den += dc;
-        r.num += nc;
+        den += dc;
+        num += nc;
     }
-    *out = r;
 }
 
 template <int RANK, bool LOGN>
@@ -176,13 +176,7 @@ __global__ __launch_bounds__(LAT_BLOCK) __attribute__((amdgpu_waves_per_eu(PEM_L
     uncertain = uncertain || !((lo + jcex) >= 1e-290);   // (written so that a NaN is uncertain as well)
     if (__ballot(uncertain)) {   // rare; under the PEM-v0 priors j_cex > 1e-6 and this never runs
         if (uncertain) {
-            Literal ex;
-            literal_sample<RANK, LOGN>(X1a, X2a, jcex, a1, a2, basis, &ex);
-            den = ex.den;
-            num = ex.num;
-            lo = ex.lo;
-#pragma unroll
-            for (int r = 0; r < RANK; ++r) lat[r] = ex.lat[r];
+            literal_sample<RANK, LOGN>(X1a, X2a, jcex, a1, a2, basis, den, num, lo, lat);
         }
     }
     // plume.py:105: invalid if alpha1 <= 0 or any j_ion <= 0 (NaN compares false); min_k fl(f_k + c) = fl(min_k f_k + c)
