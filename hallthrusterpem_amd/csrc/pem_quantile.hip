@@ -113,15 +113,15 @@ struct Lanes {
 // Every value of the array once: f(j, column, x) for the lane's j-th column.  A wave takes UNROLL consecutive row groups at a
 // time and requests all their values before it consumes the first (with one workgroup of 144 KB of LDS per CU the memory
 // latency has to be covered inside the wave).
-template <int NC, class F>
+template <int NC, int U = UNROLL, class F>
 __device__ __forceinline__ void stream_values(long long n, int m, size_t ld, const double* __restrict__ data, const Lanes& L, F f) {
     const long long wave = (long long)blockIdx.x * QWAVES + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * QWAVES;
     const long long groups = (n + L.rpw - 1) / L.rpw;
-    for (long long g0 = wave * UNROLL; g0 < groups; g0 += nwaves * UNROLL) {
-        double x[UNROLL][NC];
-        bool ok[UNROLL][NC];
+    for (long long g0 = wave * U; g0 < groups; g0 += nwaves * U) {
+        double x[U][NC];
+        bool ok[U][NC];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
+        for (int u = 0; u < U; ++u) {
             const long long row = (g0 + u) * L.rpw + L.rsub;
 #pragma unroll
             for (int j = 0; j < NC; ++j) {
@@ -131,7 +131,7 @@ __device__ __forceinline__ void stream_values(long long n, int m, size_t ld, con
             }
         }
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
+        for (int u = 0; u < U; ++u) {
 #pragma unroll
             for (int j = 0; j < NC; ++j)
                 if (ok[u][j]) f(j, L.col0 + 64 * j, x[u][j]);
@@ -737,8 +737,11 @@ __global__ __launch_bounds__(QBLOCK) __attribute__((amdgpu_waves_per_eu(bracket_
     // the sub-bin's argument; nothing else.  A NaN is flagged and otherwise counted as whatever its bits say: the column's result
     // is NaN whatever the counts are.  The general loop (taken by every wave when some bracket is a single key) compares whole
     // keys for those brackets.
+    // (four brackets or more per column: four row groups in flight per wave instead of eight -- the brackets' registers and sixteen
+    // values did not fit the 128 registers of four waves per SIMD: 9-41 spilled)
+    constexpr int U = NC >= 4 ? 4 : ((NC >= 2 && NQ >= 6) ? 2 : ((NC >= 2 && NQ >= 4) ? 4 : UNROLL));
     if (*any_single == 0) {
-        stream_values<NC>(n, m, ld, data, L, [&](int j, int c, double x) {
+        stream_values<NC, U>(n, m, ld, data, L, [&](int j, int c, double x) {
             const bool num = x == x;
             nan[j] |= num ? 0 : 1;
             const unsigned kh = key_high(x);
@@ -751,7 +754,7 @@ __global__ __launch_bounds__(QBLOCK) __attribute__((amdgpu_waves_per_eu(bracket_
             }
         });
     } else {
-        stream_values<NC>(n, m, ld, data, L, [&](int j, int c, double x) {
+        stream_values<NC, U>(n, m, ld, data, L, [&](int j, int c, double x) {
             const bool num = x == x;
             nan[j] |= num ? 0 : 1;
             const unsigned kh = key_high(x);
@@ -1097,7 +1100,7 @@ __global__ __launch_bounds__(QBLOCK) void range_hist_kernel(long long n, int m, 
 #pragma unroll
         for (int r = 0; r < NR; ++r) rs[j][r] = on ? range_scale(klo[c * NR + r], khi[c * NR + r], bins) : range_scale(1, 0, bins);
     }
-    stream_values<NC>(n, m, ld, data, L, [&](int j, int c, double x) {
+    stream_values<NC, (NC >= 4 && NR >= 4) ? 2 : UNROLL>(n, m, ld, data, L, [&](int j, int c, double x) {
         if (x == x) {
             const u64 k = key_of(x);
 #pragma unroll
