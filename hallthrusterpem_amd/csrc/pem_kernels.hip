@@ -1206,28 +1206,43 @@ struct RadiiMidArg {
 constexpr int RMID_ES = 97;                     // 16-byte words of E per sample: an odd stride, so that the G broadcast reads of an
                                                 // instruction fall on different banks (96: all on the same ones, G-way conflict)
 template <int G>
-constexpr int rmid_wave_doubles() { return ((G * RMID_ES * 2 + 1) & ~1) + RMID_TILE + 2; }
+constexpr int rmid_wave_doubles() { return ((G * RMID_ES * 2 + 1) & ~1) + RMID_TILE + 4; }   // E | tile | the samples' invalid flags (G <= 7 ints)
 
 #ifndef PEM_RMID_WAVES
 #define PEM_RMID_WAVES 3
 #endif
-template <int G>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(PEM_RMID_WAVES)))
+// (round 4) S samples share a wave in P passes: the S R (sample, radius) pairs are dealt over the lanes pass by pass -- pair
+// f = 64 p + lane is radius f % R of sample f / R -- instead of 64 / R whole samples side by side with the lanes past their radii
+// idle.  With one pass (S = 64 / R) that is the round-3 kernel: 25 radii used 50 lanes of 64 and ran at 0.78 of what 32 radii
+// reach, 33 radii 33 lanes; five samples in two passes use 125 of 128 lane slots, three samples of 33 radii 99 of 128.
+// (four samples' Gaussians and rows, or a second pass' amplitudes, leave LDS / registers for two waves per SIMD only)
+template <int S, int P>
+constexpr int rmid_waves_per_simd() { return (S >= 4 || P >= 2) ? 2 : PEM_RMID_WAVES; }
+template <int S, int P>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(rmid_waves_per_simd<S, P>())))
 void plume_rmid_kernel(PlumeIO io, RadiiMidArg radii_arg, int R, int ts) {
 #pragma clang fp contract(off)
-    const int LS = R;                           // lanes per sample: exactly its radii (G = 64 / R samples share the wave)
-    constexpr int RS = (RMID_TILE / G) & ~1;    // doubles of the tile per sample (even)
+    constexpr int RS = (RMID_TILE / S) & ~1;    // doubles of the tile per sample (even)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    double* mine = reinterpret_cast<double*>(smem_raw) + (size_t)wave * rmid_wave_doubles<G>();
-    double2* E = reinterpret_cast<double2*>(mine);   // [G][RMID_ES] {e1[k], e2[k]}
-    double* tile = mine + ((G * RMID_ES * 2 + 1) & ~1);   // [G][RS] staged rows (16-byte aligned)
-    const int grp_raw = lane / LS, r = lane - grp_raw * LS;
-    const bool lane_on = grp_raw < G;                 // the lanes past G R idle (they still take part in every shuffle)
-    const int grp = lane_on ? grp_raw : G - 1;
+    double* mine = reinterpret_cast<double*>(smem_raw) + (size_t)wave * rmid_wave_doubles<S>();
+    double2* E = reinterpret_cast<double2*>(mine);   // [S][RMID_ES] {e1[k], e2[k]}
+    double* tile = mine + ((S * RMID_ES * 2 + 1) & ~1);   // [S][RS] staged rows (16-byte aligned)
+    int* badflag = reinterpret_cast<int*>(tile + RMID_TILE);   // [S] (the two spare doubles of the tile hold up to four; S <= 7: see rmid_wave_doubles)
+    // this lane's pairs: (sample of the group, radius) per pass; a lane past the S R pairs repeats the last pair and keeps nothing
+    int grp[P], rr[P];
+    bool on[P];
+    double rad[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const int f = 64 * p + lane;
+        on[p] = f < S * R;
+        const int ff = on[p] ? f : S * R - 1;
+        grp[p] = ff / R;
+        rr[p] = ff - grp[p] * R;
+        rad[p] = radii_arg.r[rr[p]];
+    }
     const int kc = (RS - 2) / R;                      // rows per chunk: kc R + 1 <= RS - 1
-    const double rad = radii_arg.r[r];
-    const unsigned long long group_mask = (LS == 64 ? ~0ull : ((1ull << LS) - 1)) << (grp * LS);   // (R = 64 only with G = 1)
     const long long nwaves = (long long)gridDim.x * (BLOCK / WAVE);
     const bool have_T = io.T != nullptr;
     const long long ntiles = (io.n + ts - 1) / ts;
@@ -1243,30 +1258,27 @@ void plume_rmid_kernel(PlumeIO io, RadiiMidArg radii_arg, int R, int ts) {
         const double A1_l = (1.0 - c0_l) / normaliser(a1_l, 1.0 / (a1_l * a1_l), PEM_DPOLY);
         const double A2_l = c0_l / normaliser(a2_l, 1.0 / (a2_l * a2_l), PEM_DPOLY);
         const int in_tile = (int)(io.n - t * ts < ts ? io.n - t * ts : ts);
-        for (int s0 = 0; s0 < in_tile; s0 += G) {
-            // The Gaussians of the group's samples: the LS lanes of a sample take CHK consecutive angles each and advance
+        for (int s0 = 0; s0 < in_tile; s0 += S) {
+            // The Gaussians of the group's samples: the R lanes of a (sample, pass) take CHK consecutive angles each and advance
             // e_k = exp(-(k h / a)^2) by the two-term recurrence of the R = 1 kernel (e_{k+1} = e_k r_k, r_{k+1} = r_k q) from
-            // three branch-free exp per beam -- 6 instead of 2 CHK library exp() per lane (364 per group at G = 4).  A chunk in
-            // which the reference's own exp() has left the normal range (a value below 1e-290), or whose widths are not finite
-            // numbers, is evaluated literally as the reference does (plume.py:99-100), deep tail included.
-            {
-                // G = 64 / R samples per wave  =>  R > 64 / (G + 1): the longest chunk a lane can get (R >= 9 always: 11 angles)
-                constexpr int R_MIN = (WAVE / (G + 1) + 1) > RADII_SMALL + 1 ? (WAVE / (G + 1) + 1) : RADII_SMALL + 1;
-                constexpr int CHK_MAX = (NANG + R_MIN - 1) / R_MIN;
-                const int chk = (NANG + LS - 1) / LS;
-                const int k0 = r * chk;
-                const int sm = s0 + grp < in_tile ? s0 + grp : in_tile - 1;
+            // three branch-free exp per beam.  A chunk in which the reference's own exp() has left the normal range (a value
+            // below 1e-290), or whose widths are not finite numbers, is evaluated literally as the reference does
+            // (plume.py:99-100), deep tail included.  (Straight into LDS: kept in a register array first the kernel spilled.)
+            if (lane < S) badflag[lane] = 0;
+            const int chk = (NANG + R - 1) / R;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const int k0 = rr[p] * chk;
+                const int sm = s0 + grp[p] < in_tile ? s0 + grp[p] : in_tile - 1;
                 const double a1g = __shfl(a1_l, sm), a2g = __shfl(a2_l, sm);
                 const double s1 = (GRID_H * GRID_H) * (1.0 / (a1g * a1g)), s2 = (GRID_H * GRID_H) * (1.0 / (a2g * a2g));
                 double e1 = exp_nonpos(-(double)(k0 * k0) * s1), r1 = exp_nonpos(-(double)(2 * k0 + 1) * s1);
                 double e2 = exp_nonpos(-(double)(k0 * k0) * s2), r2 = exp_nonpos(-(double)(2 * k0 + 1) * s2);
                 const double q1 = exp_nonpos(-2.0 * s1), q2 = exp_nonpos(-2.0 * s2);
-                // (straight into LDS: kept in a register array first -- up to 11 pairs at 9 radii -- the kernel spilled 14-36 registers)
                 double lo = __builtin_inf();
-#pragma unroll
-                for (int i = 0; i < CHK_MAX; ++i) {
-                    if (i < chk && lane_on && k0 + i < NANG) E[grp * RMID_ES + k0 + i] = make_double2(e1, e2);
-                    if (i < chk) lo = fmin(lo, fmin(e1, e2));
+                for (int i = 0; i < chk; ++i) {
+                    if (on[p] && k0 + i < NANG) E[grp[p] * RMID_ES + k0 + i] = make_double2(e1, e2);
+                    lo = fmin(lo, fmin(e1, e2));
                     e1 *= r1;
                     r1 *= q1;
                     e2 *= r2;
@@ -1277,66 +1289,91 @@ void plume_rmid_kernel(PlumeIO io, RadiiMidArg radii_arg, int R, int ts) {
                         const int k = k0 + i;
                         const double alpha = k >= NANG - 1 ? HALF_PI : (double)k * GRID_H;
                         const double t1 = alpha / a1g, t2 = alpha / a2g;
-                        if (lane_on && k < NANG) E[grp * RMID_ES + k] = make_double2(exp(-(t1 * t1)), exp(-(t2 * t2)));
+                        if (on[p] && k < NANG) E[grp[p] * RMID_ES + k] = make_double2(exp(-(t1 * t1)), exp(-(t2 * t2)));
                     }
                 }
             }
-            // this lane's (sample, radius): amplitudes of plume.py:95-100
-            const bool smp_on = s0 + grp < in_tile;
-            const int src = smp_on ? s0 + grp : in_tile - 1;          // an idle group repeats the last sample and stores nothing
-            const long long g = t * ts + src;
-            const double a1 = __shfl(a1_l, src), A1 = __shfl(A1_l, src), A2 = __shfl(A2_l, src);
-            const double n_neutral = __shfl(nn_l, src), sigma = io.sigma[g];
-            const double I_B0 = io.I_B0[g], thrust = have_T ? io.T[g] : 0.0;
-            const double decay = exp(-rad * n_neutral * sigma);
-            const double j_cex = I_B0 * (1.0 - decay) / (2.0 * PEM_PI * (rad * rad));
-            const double base = I_B0 * decay / (rad * rad);
-            const double b1 = base * A1, b2 = base * A2;
+            // this lane's (sample, radius) pairs: amplitudes of plume.py:95-100
+            bool smp_on[P];
+            long long g[P];
+            double b1[P], b2[P], jcx[P], den[P], num[P], thrust[P];
+            bool bad[P];
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                smp_on[p] = on[p] && s0 + grp[p] < in_tile;
+                const int src = s0 + grp[p] < in_tile ? s0 + grp[p] : in_tile - 1;      // an idle pair repeats the last sample and stores nothing
+                g[p] = t * ts + src;
+                const double A1 = __shfl(A1_l, src), A2 = __shfl(A2_l, src);
+                const double n_neutral = __shfl(nn_l, src), sigma = io.sigma[g[p]];
+                const double I_B0 = io.I_B0[g[p]];
+                thrust[p] = have_T ? io.T[g[p]] : 0.0;
+                const double decay = exp(-rad[p] * n_neutral * sigma);
+                jcx[p] = I_B0 * (1.0 - decay) / (2.0 * PEM_PI * (rad[p] * rad[p]));
+                const double base = I_B0 * decay / (rad[p] * rad[p]);
+                b1[p] = base * A1;
+                b2[p] = base * A2;
+                den[p] = 0.0;
+                num[p] = 0.0;
+                bad[p] = false;
+            }
             wave_lds_sync();
-            double den = 0.0, num = 0.0;
-            bool bad = false;
             for (int k0 = 0; k0 < NANG; k0 += kc) {
                 const int rows = NANG - k0 < kc ? NANG - k0 : kc;
-                {
-                    // where this lane's run starts in j_ion: the LDS copy gets the same parity
-                    const double* gdst = io.j_ion + ((size_t)g * NANG + k0) * R;
-                    double* run = tile + grp * RS + (int)((reinterpret_cast<uintptr_t>(gdst) >> 3) & 1);
-                    if (lane_on) {
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    // where this pair's run starts in j_ion: the LDS copy gets the same parity
+                    const double* gdst = io.j_ion + ((size_t)g[p] * NANG + k0) * R;
+                    double* run = tile + grp[p] * RS + (int)((reinterpret_cast<uintptr_t>(gdst) >> 3) & 1);
+                    if (on[p]) {
 #pragma unroll 4
                         for (int kk = 0; kk < rows; ++kk) {
                             const int k = k0 + kk;
-                            const double2 ee = E[grp * RMID_ES + k];
-                            const double f = b1 * ee.x + b2 * ee.y;      // j_beam + j_scat
-                            const double ji = f + j_cex;                  // plume.py:102
-                            run[kk * R + r] = ji;
-                            den = __builtin_fma(PEM_SIMPSON_CDEN[k], f, den);
-                            num = __builtin_fma(PEM_SIMPSON_CNUM[k], f, num);
-                            bad |= ji <= 0.0;
+                            const double2 ee = E[grp[p] * RMID_ES + k];
+                            const double f = b1[p] * ee.x + b2[p] * ee.y;      // j_beam + j_scat
+                            const double ji = f + jcx[p];                      // plume.py:102
+                            run[kk * R + rr[p]] = ji;
+                            den[p] = __builtin_fma(PEM_SIMPSON_CDEN[k], f, den[p]);
+                            num[p] = __builtin_fma(PEM_SIMPSON_CNUM[k], f, num[p]);
+                            bad[p] |= ji <= 0.0;
                         }
                     }
                 }
                 wave_lds_sync();
                 // the runs leave one after the other, the whole wave on each
-                for (int gi = 0; gi < G; ++gi) {
+                for (int gi = 0; gi < S; ++gi) {
                     if (s0 + gi >= in_tile) break;
                     double* dst = io.j_ion + ((size_t)(t * ts + s0 + gi) * NANG + k0) * R;
                     stream_run(tile + gi * RS + (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1), dst, rows * R, lane);
                 }
                 wave_lds_sync();
             }
-            double cos_div = num / den;   // plume.py:124-127
-            if (cos_div == __builtin_inf()) cos_div = __builtin_nan("");
-            const unsigned long long any_bad = __ballot(bad && lane_on && smp_on);
-            const bool invalid = a1 <= 0.0 || (any_bad & group_mask) != 0;      // plume.py:105
-            if (lane_on && smp_on) {
-                io.div[(size_t)g * R + r] = acos(cos_div);
-                if (have_T) io.Tc[(size_t)g * R + r] = thrust * cos_div;
+            // plume.py:105: a sample is invalid if alpha1 <= 0 or any of its values is <= 0 -- its pairs sit on several lanes and passes
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+                if (smp_on[p] && bad[p]) badflag[grp[p]] = 1;
+            wave_lds_sync();
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                double cos_div = num[p] / den[p];   // plume.py:124-127
+                if (cos_div == __builtin_inf()) cos_div = __builtin_nan("");
+                const int src = s0 + grp[p] < in_tile ? s0 + grp[p] : in_tile - 1;
+                const bool invalid = __shfl(a1_l, src) <= 0.0 || badflag[grp[p]] != 0;
+                if (smp_on[p]) {
+                    io.div[(size_t)g[p] * R + rr[p]] = acos(cos_div);
+                    if (have_T) io.Tc[(size_t)g[p] * R + rr[p]] = thrust[p] * cos_div;
+                    if (io.invalid && rr[p] == 0) io.invalid[g[p]] = (uint8_t)invalid;
+                }
             }
-            if (smp_on && invalid) {   // plume.py:106: the whole block becomes 1e-20 (rare: a second pass over it)
-                double* blk = io.j_ion + (size_t)g * NANG * R;
-                for (int idx = r; idx < NANG * R; idx += LS) blk[idx] = 1e-20;
+            // plume.py:106: the whole block of an invalid sample becomes 1e-20 (rare: a second pass over it, the whole wave on each)
+            for (int gi = 0; gi < S; ++gi) {
+                if (s0 + gi >= in_tile) break;
+                const bool invalid = __shfl(a1_l, s0 + gi) <= 0.0 || badflag[gi] != 0;
+                if (invalid) {
+                    double* blk = io.j_ion + (size_t)(t * ts + s0 + gi) * NANG * R;
+                    for (int idx = lane; idx < NANG * R; idx += WAVE) blk[idx] = 1e-20;
+                }
             }
-            if (io.invalid && smp_on && r == 0) io.invalid[g] = (uint8_t)invalid;
+            wave_lds_sync();
         }
         wave_lds_sync();
     }
@@ -2174,43 +2211,81 @@ int pem_plume_f64_dev(size_t n, int n_radii, const double* radii, double torr2pa
         return PEM_OK;
     }
     static const bool use_rmid = getenv("PEM_RADII_MID") ? atoi(getenv("PEM_RADII_MID")) != 0 : true;
-    // (read per call: tests walk through the instantiations; at most five samples per wave -- 11 radii or more -- are built)
+    // (read per call: tests walk through the instantiations)
     int rmid_min = getenv("PEM_RMID_MIN") ? atoi(getenv("PEM_RMID_MIN")) : 17;
     if (rmid_min < WAVE / RMID_G_MAX + 1) rmid_min = WAVE / RMID_G_MAX + 1;
     if (use_rmid && n_radii >= rmid_min && n_radii > RADII_SMALL && n_radii <= RMID_MAX) {
-        // 64 / R samples in flight per wave, rows staged in LDS, line-aligned 16-byte stores (plume_rmid_kernel): 3.5-5.2 TB/s
-        // of output for 17..64 radii against 3.3-4.9 for the wave-per-sample kernel below (25 radii: 3.8-4.0 against 3.2-3.35).
-        // From 11 radii on (PEM_RMID_MIN=11) it works but gains nothing over the kernel below (2.9 / 3.3 / 3.9 against 2.9 / 3.1 /
-        // 4.1 TB/s at 9 / 12 / 16 radii): seven samples share the 8 KB of staged rows, and their 1.1 KB runs pay the run's head /
-        // body / tail code 42 times per group (profiles/radii_mid_r03.txt)
+        // S samples in flight per wave in P passes, rows staged in LDS, line-aligned 16-byte stores (plume_rmid_kernel).  The pair
+        // (S, P) of the instantiated ones that fills the most lane slots, S R / (64 P): 25 radii -> five samples in two passes (125
+        // of 128; round 3: two samples in one, 50 of 64), 33 -> three in two (99 of 128; one sample before: 33 of 64).
+        // From 11 radii on (PEM_RMID_MIN=11) it works but gains nothing over the kernel below (profiles/radii_mid_r03.txt).
+        // Instantiated: one pass.  Two- and three-pass packings (-DPEM_RMID_MULTIPASS=1) fill 86-98 % of the lane slots where one pass
+        // fills 52-80 %, and measured SLOWER at every radius count (25 radii: 3.25 against 3.69 TB/s, 33: 3.59 against 4.12, 44: 3.58
+        // against 4.33; profiles/radii_mid_r04.txt): more samples share the 8 KB of staged rows, so a sample's runs get shorter (200
+        // doubles instead of 500 at 25 radii) and the head / body / tail of a run and the two syncs around it are paid 12 times per
+        // sample instead of 5 -- the kernel's bound is that phase structure, not idle lanes.  What separates 32 / 40 / 48 / 64 radii
+        // (4.6-4.9 TB/s) from their neighbours (3.7-4.3) is the alignment of a sample's rows to 128-byte lines, not the lane count.
+#if defined(PEM_RMID_MULTIPASS) && PEM_RMID_MULTIPASS
+        static const int combos[][2] = {{1, 1}, {2, 1}, {3, 1}, {4, 1}, {5, 1}, {3, 2}, {5, 2}, {6, 2}, {7, 2}, {4, 3}, {6, 3}, {7, 3}};
+#else
+        static const int combos[][2] = {{1, 1}, {2, 1}, {3, 1}, {4, 1}, {5, 1}};
+#endif
+        int S = 1, P = 1;
+        double best = 0.0;
+        for (const auto& c : combos) {
+            if (c[0] * n_radii > WAVE * c[1] || (c[1] > 1 && c[0] * n_radii <= WAVE * (c[1] - 1))) continue;   // the pairs fill 64 (P - 1) + 1 .. 64 P slots
+            if ((RMID_TILE / c[0] - 2) / n_radii < 1) continue;                                               // a staged row per sample must fit
+            const double eff = (double)(c[0] * n_radii) / (WAVE * c[1]) - 0.02 * (c[1] - 1);                  // (a pass more has to pay for itself)
+            if (eff > best) {
+                best = eff;
+                S = c[0];
+                P = c[1];
+            }
+        }
+        if (const char* e = getenv("PEM_RMID_SP")) {                                   // tests / experiments: "S,P" of an instantiated pair
+            int es = 0, ep = 0;
+            if (sscanf(e, "%d,%d", &es, &ep) == 2 && es * n_radii <= WAVE * ep && (RMID_TILE / es - 2) / n_radii >= 1)
+                for (const auto& c : combos)
+                    if (c[0] == es && c[1] == ep) {
+                        S = es;
+                        P = ep;
+                    }
+        }
         RadiiMidArg ra;
         for (int r = 0; r < RMID_MAX; ++r) ra.r[r] = r < n_radii ? radii[r] : 1.0;
         int ts = WAVE;                             // samples per wave tile: fewer when the batch is small
         while (ts > 8 && (n + ts - 1) / ts < 256 * 32) ts >>= 1;
-        {   // whole groups only: G = 64 / R samples are in flight at a time, a tile of 8 would leave a second group of one
-            const int G = WAVE / n_radii;
-            ts = ts / G * G;
-            if (ts < 2 * G) ts = 2 * G <= WAVE ? 2 * G : G;
-        }
+        ts = ts / S * S;                           // whole groups only
+        if (ts < 2 * S) ts = 2 * S <= WAVE ? 2 * S : S;
         if (const char* e = getenv("PEM_RMID_TS")) ts = atoi(e);                      // experiments
+        if (ts < 1 || ts > WAVE) return fail(PEM_ERR_INVALID_ARG, "pem_plume: PEM_RMID_TS must be 1..64");
         const size_t ntiles = (n + ts - 1) / ts;
         int cus = 256;
         HIP_TRY(pem::device_cus(&cus));
         size_t blocks = (ntiles + BLOCK / WAVE - 1) / (BLOCK / WAVE);
-#define PEM_RMID_LAUNCH(G_)                                                                                         \
+#define PEM_RMID_LAUNCH(S_, P_)                                                                                     \
     do {                                                                                                            \
-        const size_t lds = (size_t)(BLOCK / WAVE) * rmid_wave_doubles<G_>() * 8;                                    \
+        const size_t lds = (size_t)(BLOCK / WAVE) * rmid_wave_doubles<S_>() * 8;                                    \
         size_t per_cu = (160 * 1024) / lds;                                                                         \
-        if (per_cu > 4) per_cu = 4;                                                                                 \
+        if (per_cu > (size_t)rmid_waves_per_simd<S_, P_>()) per_cu = rmid_waves_per_simd<S_, P_>();                 \
         blocks = balanced_grid(blocks, (size_t)cus * per_cu);                                                       \
-        hipLaunchKernelGGL(plume_rmid_kernel<G_>, dim3((unsigned)blocks), dim3(BLOCK), lds, st, io, ra, n_radii, ts); \
+        hipLaunchKernelGGL((plume_rmid_kernel<S_, P_>), dim3((unsigned)blocks), dim3(BLOCK), lds, st, io, ra, n_radii, ts); \
     } while (0)
-        switch (WAVE / n_radii) {          // samples in flight per wave
-            case 1: PEM_RMID_LAUNCH(1); break;
-            case 2: PEM_RMID_LAUNCH(2); break;
-            case 3: PEM_RMID_LAUNCH(3); break;
-            case 4: PEM_RMID_LAUNCH(4); break;
-            default: PEM_RMID_LAUNCH(5); break;          // (64 / R <= RMID_G_MAX: checked above)
+        switch (S * 10 + P) {
+            case 11: PEM_RMID_LAUNCH(1, 1); break;
+            case 21: PEM_RMID_LAUNCH(2, 1); break;
+            case 31: PEM_RMID_LAUNCH(3, 1); break;
+            case 41: PEM_RMID_LAUNCH(4, 1); break;
+#if defined(PEM_RMID_MULTIPASS) && PEM_RMID_MULTIPASS
+            case 32: PEM_RMID_LAUNCH(3, 2); break;
+            case 52: PEM_RMID_LAUNCH(5, 2); break;
+            case 62: PEM_RMID_LAUNCH(6, 2); break;
+            case 72: PEM_RMID_LAUNCH(7, 2); break;
+            case 43: PEM_RMID_LAUNCH(4, 3); break;
+            case 63: PEM_RMID_LAUNCH(6, 3); break;
+            case 73: PEM_RMID_LAUNCH(7, 3); break;
+#endif
+            default: PEM_RMID_LAUNCH(5, 1); break;
         }
 #undef PEM_RMID_LAUNCH
         HIP_TRY(hipGetLastError());

@@ -49,6 +49,27 @@ __global__ __launch_bounds__(256) void writer_once_xcd(f64x2* __restrict__ out, 
     f64x2* dst = out + t * pieces_per_tile * 64 + lane;
     for (int p = 0; p < pieces_per_tile; ++p) __builtin_nontemporal_store(v, dst + (long long)p * 64);
 }
+// E9 (round 4): workgroup-cooperative rounds.  A workgroup still owns four consecutive 46-KB tiles (one per wave's
+// prelude), but writes them ONE AFTER THE OTHER, all four waves on the same tile -- wave w its quarter (12 / 12 / 11 / 11 KB), a
+// workgroup barrier between tiles as the real kernel would need one to publish the next tile's parameters: a workgroup is then one
+// sequential 184-KB stream (64 per XCD) where E8's four waves are four streams 46 KB apart (256 per XCD).  Same bytes, same order of
+// workgroups over the XCDs as E8.
+__global__ __launch_bounds__(256) void writer_coop_xcd(f64x2* __restrict__ out, long long pieces_total, int pieces_per_tile, int barrier) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const unsigned q = gridDim.x >> 3, r = gridDim.x & 7, x = blockIdx.x & 7;
+    const long long vb = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (blockIdx.x >> 3);
+    const f64x2 v = {1.0 + lane, 2.0};
+    const int base = pieces_per_tile / 4, extra = pieces_per_tile & 3;
+    const int p0 = w * base + (w < extra ? w : extra), np = base + (w < extra ? 1 : 0);
+    for (int i = 0; i < 4; ++i) {
+        const long long t = vb * 4 + i;
+        if ((t + 1) * pieces_per_tile <= pieces_total) {
+            f64x2* dst = out + (t * pieces_per_tile + p0) * 64 + lane;
+            for (int p = 0; p < np; ++p) __builtin_nontemporal_store(v, dst + (long long)p * 64);
+        }
+        if (barrier) __syncthreads();
+    }
+}
 // E1: one-shot, 1 KB per wave, but workgroup b writes chunk perm(b): the address order of the dispatch order is destroyed
 __global__ __launch_bounds__(256) void writer_scrambled(f64x2* __restrict__ out, long long nblocks, long long mult) {
     const int lane = threadIdx.x & 63;
@@ -204,6 +225,20 @@ int main() {
         snprintf(what, sizeof what, "E8 one-shot, ONE tile of %3d KB per wave, XCD-contiguous tile order (nt stores)", ppt);
         timeit([&](int i) { hipLaunchKernelGGL(writer_once_xcd, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, 0, buf[i % NB], use, ppt); }, what,
                use * 1024.0);
+    }
+    for (int barrier : {0, 1}) {            // E9 beside E8 at the kernel's tile size, interleaved three times
+        for (int rep = 0; rep < 3; ++rep) {
+            const int ppt = 46;
+            const long long use = pieces / ppt * ppt, tiles = use / ppt;
+            char what[200];
+            snprintf(what, sizeof what, "E8 one-shot, ONE tile of  46 KB per wave, XCD-contiguous tile order (nt stores) [A/B %d]", rep);
+            timeit([&](int i) { hipLaunchKernelGGL(writer_once_xcd, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, 0, buf[i % NB], use, ppt); }, what,
+                   use * 1024.0);
+            snprintf(what, sizeof what, "E9 one-shot, workgroup writes its four 46-KB tiles one after the other, four waves per tile%s [A/B %d]",
+                     barrier ? ", barrier between tiles" : "", rep);
+            timeit([&](int i) { hipLaunchKernelGGL(writer_coop_xcd, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, 0, buf[i % NB], use, ppt, barrier); },
+                   what, use * 1024.0);
+        }
     }
     return 0;
 }
