@@ -1014,24 +1014,65 @@ __global__ __launch_bounds__(QBLOCK) void record_hist_kernel(const pem::Record* 
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < lists * bins; i += QBLOCK) {
-        const unsigned v = lds_hist[i];
-        if (v) atomicAdd(&hist[i], v);
+    // the workgroup's own counts, whole (no atomics): summed over the workgroups by record_reduce_kernel, and read again -- per chosen
+    // sub-bin -- by record_offsets_kernel, which gives every workgroup its own place in every list
+    unsigned* mine = hist + (size_t)blockIdx.x * lists * bins;
+    for (int i = threadIdx.x; i < lists * bins; i += QBLOCK) mine[i] = lds_hist[i];
+}
+
+__global__ __launch_bounds__(256) void record_reduce_kernel(const unsigned* __restrict__ part, int groups, int cells, unsigned* __restrict__ hist) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= cells) return;
+    unsigned sum = 0;
+    for (int g = 0; g < groups; ++g) sum += part[(size_t)g * cells + i];
+    hist[i] = sum;
+}
+
+// One wave per target that owns a list: where each workgroup of the copy pass appends its hits -- the exclusive prefix, over the
+// workgroups, of their counts in the list's sub-bin (record_hist_kernel's own histograms).  The copy pass then needs no global
+// atomic (it drew one per hit: 5.6e5 returning atomics on 910 addresses, 0.36 ms for 580 MB of records).
+__global__ __launch_bounds__(64) void record_offsets_kernel(int nt, int bins, const Target* __restrict__ tg, const unsigned* __restrict__ part,
+                                                             int groups, int cells, unsigned* __restrict__ woff) {
+    const int i = blockIdx.x, lane = threadIdx.x, targets = gridDim.x;
+    const Target T = tg[i];
+    const int t = i % nt;
+    const bool own = !T.done && T.owner == t;
+    const int cell = (i / 2) * bins + (own ? T.bin2 : 0);      // targets 2q, 2q + 1 of column c belong to list c nq + q = i / 2
+    unsigned base = 0;
+    for (int g0 = 0; g0 < groups; g0 += 64) {
+        const int g = g0 + lane;
+        const unsigned v = (own && g < groups) ? part[(size_t)g * cells + cell] : 0u;
+        unsigned incl = v;
+#pragma unroll
+        for (int sh = 1; sh < 64; sh <<= 1) {
+            const unsigned up = __shfl_up(incl, sh);
+            if (lane >= sh) incl += up;
+        }
+        if (g < groups) woff[(size_t)g * targets + i] = base + incl - v;
+        base += __shfl(incl, 63);
     }
 }
 
 template <int NQ>
 __global__ __launch_bounds__(QBLOCK) void record_compact_kernel(const pem::Record* __restrict__ rec, const unsigned* __restrict__ rec_count, unsigned cap,
                                                                  unsigned waves, const Bracket* __restrict__ br, int lists, Target* __restrict__ tg,
-                                                                 u64* __restrict__ cand) {
+                                                                 const unsigned* __restrict__ woff, u64* __restrict__ cand) {
     __shared__ uint4 s_br[REC_LISTS_MAX];                       // {loh, words, mult, -}
     __shared__ int2 s_bin[REC_LISTS_MAX];                       // the sub-bins the quantile's two targets collect (-1: not a list owner)
+    __shared__ unsigned s_cur[2 * REC_LISTS_MAX];               // this workgroup's cursor in every target's list (from record_offsets_kernel)
+    __shared__ u64 s_base[2 * REC_LISTS_MAX];                   // the lists' starts in `cand`
+    const unsigned* my_off = woff + (size_t)blockIdx.x * 2 * lists;
     for (int i = threadIdx.x; i < lists; i += QBLOCK) {
         s_br[i] = make_uint4(br[i].loh, br[i].words, br[i].mult, 0u);
         const Target &T0 = tg[2 * i], &T1 = tg[2 * i + 1];     // targets 2q, 2q + 1 of column c sit at (c nq + q) 2
         s_bin[i] = make_int2((!T0.done && (T0.owner & 1) == 0) ? T0.bin2 : -1, (!T1.done && (T1.owner & 1) == 1) ? T1.bin2 : -1);
+        s_cur[2 * i] = my_off[2 * i];
+        s_cur[2 * i + 1] = my_off[2 * i + 1];
+        s_base[2 * i] = T0.offset;
+        s_base[2 * i + 1] = T1.offset;
     }
     __syncthreads();
+    // (the same records as this workgroup counted in record_hist_kernel: same grid, same walk)
     for (unsigned w = blockIdx.x; w < waves; w += gridDim.x) {
         const unsigned cnt = rec_count[w] < cap ? rec_count[w] : cap;
         const pem::Record* r = rec + (size_t)w * cap;
@@ -1048,12 +1089,15 @@ __global__ __launch_bounds__(QBLOCK) void record_compact_kernel(const pem::Recor
                 const int bin = (int)__umulhi(t, mult);
                 const int2 want = s_bin[cq];
                 const int hit = want.x == bin ? 0 : (want.y == bin ? 1 : -1);
-                if (hit >= 0) {
-                    Target& T = tg[2 * cq + hit];
-                    cand[T.offset + atomicAdd(&T.cursor, 1ull)] = e[u].key;
-                }
+                if (hit >= 0) cand[s_base[2 * cq + hit] + atomicAdd(&s_cur[2 * cq + hit], 1u)] = e[u].key;
             }
         }
+    }
+    __syncthreads();
+    // what this workgroup appended, onto the lists' counters: select_kernel compares them with the counts (the "incomplete" check)
+    for (int i = threadIdx.x; i < 2 * lists; i += QBLOCK) {
+        const unsigned wrote = s_cur[i] - my_off[i];
+        if (wrote) atomicAdd(&tg[i].cursor, (u64)wrote);
     }
 }
 
@@ -1224,6 +1268,8 @@ static int quantiles_impl(size_t n, int m, const double* data, size_t ld, size_t
     static size_t ws_cap = 0, cand_cap = 0, rec_cap = 0;
     static u64* cand_buf = nullptr;
     static pem::Record* rec_buf = nullptr;
+    static unsigned* part_buf = nullptr;              // fused form: the record histograms of every workgroup | their offsets into the lists
+    static size_t part_cap = 0;
     static int ws_dev = -1;
     std::lock_guard<std::mutex> lock(mu);
     int dev = 0;
@@ -1239,6 +1285,11 @@ static int quantiles_impl(size_t n, int m, const double* data, size_t ld, size_t
             (void)hipFree(rec_buf);
             rec_buf = nullptr;
             rec_cap = 0;
+        }
+        if (part_buf && dev != ws_dev) {
+            (void)hipFree(part_buf);
+            part_buf = nullptr;
+            part_cap = 0;
         }
         ws_buf = nullptr;
         ws_cap = 0;
@@ -1462,12 +1513,23 @@ static int quantiles_impl(size_t n, int m, const double* data, size_t ld, size_t
             if (int rc = fused->count(cio, st)) return cleanup(rc);
             int cus = 256;
             Q_TRY(pem::device_cus(&cus));
+            const int cells = m * nq * binsA;
+            {
+                const size_t need = (size_t)cus * cells + (size_t)cus * m * nt;
+                if (part_cap < need) {
+                    if (part_buf) (void)hipFree(part_buf);
+                    part_buf = nullptr;
+                    part_cap = 0;
+                    Q_TRY(hipMalloc(&part_buf, need * sizeof(unsigned)));
+                    part_cap = need;
+                }
+            }
 #define Q_RECHIST(NQ_)                                                                                                       \
     do {                                                                                                                     \
         static pem::LdsAttrOnce attr;                                                                                        \
         Q_TRY(attr.ensure(reinterpret_cast<const void*>(record_hist_kernel<NQ_>), 148 * 1024)); /* (+ 12 KB of static tables) */ \
         hipLaunchKernelGGL(record_hist_kernel<NQ_>, dim3((unsigned)cus), blk, (size_t)m * nq * binsA * 4, st, rec_buf, rec_count, rcap, fused_waves, \
-                           br, m * nq, binsA, histA);                                                                        \
+                           br, m * nq, binsA, part_buf);                                                                     \
     } while (0)
             switch (nq) {
                 case 1: Q_RECHIST(1); break;
@@ -1478,6 +1540,7 @@ static int quantiles_impl(size_t n, int m, const double* data, size_t ld, size_t
                 default: Q_RECHIST(6); break;
             }
 #undef Q_RECHIST
+            hipLaunchKernelGGL(record_reduce_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, part_buf, cus, cells, histA);
             hipLaunchKernelGGL(record_total_check_kernel, dim3(1), blk, 0, st, rec_count, rcap, fused_waves, histA, m * nq * binsA, inconsistent, prod_flags);
         }
         hipLaunchKernelGGL(decide_bracket_kernel, dim3((unsigned)(m * nt)), dim3(64), 0, st, nt, col, br, below, histA, binsA, tg, outside);
@@ -1504,8 +1567,10 @@ static int quantiles_impl(size_t n, int m, const double* data, size_t ld, size_t
             } else {
                 int cus = 256;
                 Q_TRY(pem::device_cus(&cus));
+                unsigned* woff = part_buf + (size_t)cus * m * nq * binsA;
+                hipLaunchKernelGGL(record_offsets_kernel, dim3((unsigned)(m * nt)), dim3(64), 0, st, nt, binsA, tg, part_buf, cus, m * nq * binsA, woff);
 #define Q_RECCOMPACT(NQ_) \
-    hipLaunchKernelGGL(record_compact_kernel<NQ_>, dim3((unsigned)(cus * 2)), blk, 0, st, rec_buf, rec_count, rcap, fused_waves, br, m * nq, tg, cand)
+    hipLaunchKernelGGL(record_compact_kernel<NQ_>, dim3((unsigned)cus), blk, 0, st, rec_buf, rec_count, rcap, fused_waves, br, m * nq, tg, woff, cand)
                 switch (nq) {
                     case 1: Q_RECCOMPACT(1); break;
                     case 2: Q_RECCOMPACT(2); break;

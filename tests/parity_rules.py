@@ -12,7 +12,12 @@ the result that is tau * cond with cond = sum|t_i| / |sum t_i|.  No implementati
 exp and libm's differ in the last bit) can do better than that, so a result is accepted when
 
   |got - want| <= 1e-10 |want|  +  TAU * sum|t_i|        (j_ion;   + the 1 - exp(-x) floor below)
-  cos_div: relative error <= 4 eps + TAU * (cond_den + cond_num - 2)      (4 eps = 8 ulp of a number in [0.5, 1))
+  cos_div: relative error <= 4 eps + TAU * (cond_den + cond_num - 2) + 1.5 eps (u2_den + u2_num)
+           (4 eps = 8 ulp of a number in [0.5, 1); u2 = the |term|-weighted mean of u^2 = (alpha / a)^2 over a Simpson sum: a term
+           g = exp(-u^2) is reproduced to 1.5 eps u^2 at best -- first bullet below -- and a sum WITHOUT cancellation inherits the
+           weighted mean of its terms' errors, which the TAU x (cond - 1) part does not cover: for a beam one grid step wide the
+           terms that carry the sums have u^2 = 1 .. 5 and the two sums differ by 8 eps between correct evaluations -- nothing
+           anywhere else, 2e-10 of a divergence angle of 0.003 rad (seed 5160, round 4: arccos at the pole); wide beams: +3 eps)
 
 with the term sizes taken from the oracle (oracle_plume_terms_f64), per entry -- not a blanket tolerance for a class of
 samples.  TAU = 3e-13 is the agreement two correct fp64 evaluations of one TERM can be held to here:
@@ -48,6 +53,13 @@ def angle_grid():
     return a
 
 
+def _simpson_weights():
+    """w with scipy.integrate.simpson(y, x=angle_grid()) == w @ y (the rule is linear in y)"""
+    from scipy.integrate import simpson
+    a = angle_grid()
+    return np.array([simpson(np.eye(NANGLE)[m], x=a) for m in range(NANGLE)])
+
+
 def plume_bounds(terms: dict, I_B0):
     """terms: oracle_ctypes.plume_terms(...).  Returns per-entry absolute slack for j_ion (n, 91, R), the condition
     numbers, the allowed relative error of cos_div (n, R) and the mask of (sample, radius) pairs whose div_angle / T_c are
@@ -64,7 +76,17 @@ def plume_bounds(terms: dict, I_B0):
         j_terms = beams + (1.0 + np.abs(decay)) * unit          # j_cex is itself the difference unit * (1 - decay)
         cond_den = terms['den_abs'] / np.abs(terms['den'])
         cond_num = terms['num_abs'] / np.abs(terms['num'])
-        cos_rel = 4 * EPS + TAU * np.maximum(cond_den + cond_num - 2.0, 0.0)
+        # the |term|-weighted mean of u^2 over the two Simpson sums (weights folded as plume.py:117-123 applies them: the profile
+        # flipped against cos(alpha) [sin(alpha)], scipy's composite weights w)
+        w = _simpson_weights()
+        cden = (w * np.cos(angle_grid()))[::-1][None, :, None]
+        cnum = (w * np.cos(angle_grid()) * np.sin(angle_grid()))[::-1][None, :, None]
+        u1sq = ((al / terms['a1'][:, None]) ** 2)[:, :, None]
+        u2sq = ((al / terms['a2'][:, None]) ** 2)[:, :, None]
+        t1, t2 = np.abs(X1) * g1, np.abs(X2) * g2
+        wsum = lambda c: np.nan_to_num(np.sum(np.abs(c) * (t1 * u1sq + t2 * u2sq), axis=1) /                       # noqa: E731
+                                       np.sum(np.abs(c) * (t1 + t2), axis=1), nan=0.0, posinf=0.0)
+        cos_rel = 4 * EPS + TAU * np.maximum(cond_den + cond_num - 2.0, 0.0) + 1.5 * EPS * (wsum(cden) + wsum(cnum))
         cos_rel = np.where(np.isfinite(cos_rel), cos_rel, np.inf)              # den == 0 or a NaN amplitude: nothing to hold
         base = np.asarray(I_B0)[:, None] * terms['decay'] / terms['radii'][None, :] ** 2
         denormal = (np.abs(base) < 1e-280) & (base != 0.0)

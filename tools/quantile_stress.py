@@ -44,7 +44,7 @@ for case in range(args.cases):
     elif kind == 5:                                  # denormals and huge values
         a[:, 0] *= 1e-310
         a[::2, -1] *= 1e300
-    pcts = [[25.0, 75.0], [5.0, 50.0, 95.0], [50.0], [0.0, 100.0], list(np.round(rng.uniform(0, 100, int(rng.integers(1, 6))), 3))][int(rng.integers(0, 5))]
+    pcts = [[25.0, 75.0], [5.0, 50.0, 95.0], [50.0], [0.0, 100.0], list(np.round(rng.uniform(0, 100, int(rng.integers(1, 8))), 3)), [25.0, 75.0, 5.0, 50.0, 95.0]][int(rng.integers(0, 6))]
     os.environ['PEM_QUANTILE_PILOT'] = str(int(rng.choice([2, 7, 32, 64] if args.pilot_only else [0, 2, 7, 32, 64])))
     os.environ['PEM_QUANTILE_PILOT_MIN'] = str(int(rng.choice([1, 1000] if args.pilot_only else [1, 1000, 1 << 25])))
     d = torch.from_numpy(np.ascontiguousarray(a)).cuda()
