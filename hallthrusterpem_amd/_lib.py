@@ -15,6 +15,7 @@ LIB_PATH = PKG / 'libpem_hip.so'
 
 PEM_OK, PEM_ERR_INVALID_ARG, PEM_ERR_HIP, PEM_ERR_NO_DEVICE = 0, 1, 2, 3
 NANGLE = 91
+FUSED_LATENT_MAX_RANK = 8     # PEM_FUSED_LATENT_MAX_RANK (include/pem_hip.h): latents the fused model -> compression launch keeps
 
 _dp = C.c_void_p          # every array crosses the boundary as a raw pointer
 _sz = C.c_size_t

@@ -239,9 +239,10 @@ constexpr int DIRECT_STEPS = 24;     // dof <= 96
 // instruction: 12 loads of 16 rows x 64 contiguous bytes per tile instead of 24 of 16 x 32.
 __device__ __forceinline__ constexpr int direct_k(int step, int quad) { return 8 * (step >> 1) + 2 * quad + (step & 1); }
 // BREG: the lane's 24 basis values live in registers for the whole launch (160 VGPRs, three waves per SIMD); otherwise they
-// are re-read from LDS per tile (conflict-free 8-byte reads) and the kernel is compiled for four waves per SIMD.
+// are re-read from LDS per tile (conflict-free 8-byte reads; PEM_SVD_BREG=0, an A/B switch).  Both are compiled for three waves
+// per SIMD: at four the LDS form spilled 2-12 registers to scratch (round 4: no kernel of the library uses scratch).
 template <int MODE, bool BREG>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BREG ? 3 : 4)))
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
 void svd_compress_direct_kernel(long long n, int dof, int r, double scale, const double* __restrict__ field,
                                 const double* __restrict__ basis, double* __restrict__ latent) {
     __shared__ __attribute__((aligned(16))) double logtab[MODE == PEM_NORM_LOG10 ? pem::LOG_TABLE_DOUBLES : 2];
@@ -477,7 +478,7 @@ int pem_svd_compress_f64_dev(size_t n, int dof, int rank, int norm, double norm_
     if (dof <= 4 * DIRECT_STEPS && !getenv("PEM_SVD_TILED")) {
         size_t dblocks = ((n + 15) / 16 + WAVES - 1) / WAVES;
         static const bool breg = getenv("PEM_SVD_BREG") ? atoi(getenv("PEM_SVD_BREG")) != 0 : true;
-        const size_t per_cu = breg ? 3 : 4;           // persistent: workgroups (of four waves) resident per CU, by registers
+        const size_t per_cu = 3;                      // persistent: workgroups (of four waves) resident per CU, by registers
         dblocks = balanced_blocks(dblocks, 256 * per_cu);
         hipStream_t st = static_cast<hipStream_t>(stream);
 #define PEM_SVD_DIRECT(MODE_)                                                                                                   \

@@ -138,12 +138,15 @@ class SparseGridSurrogate:
     def _true_outputs(self, inputs: dict, n: int):
         """[n][n_out] CUDA tensor: the true model's scalars and -- fused, the profile is never stored -- the field's latents"""
         import torch
-        batch = CoupledBatch(n, device=self.device, profile=False)
+        fused = self.field and self.compression.rank <= _lib.FUSED_LATENT_MAX_RANK
+        batch = CoupledBatch(n, device=self.device, profile=bool(self.field) and not fused)
         batch.set_inputs(inputs)
-        if self.field:
+        if fused:
             lat = batch.run_latent(self.compression)                            # [n][rank]; V_cc / div_angle / T_c written as by run()
         else:
             batch.run()
+            if self.field:                                                      # more latents than the fused launch keeps in registers:
+                lat = self.compression.compress(batch.j_ion)                    # profile stored once, pem_svd_compress_f64_dev over it
         o = batch.outputs()
         cols = [o[k] for k in self.scalars]
         y = torch.stack(cols, dim=1) if cols else torch.empty((n, 0), dtype=torch.float64, device=self.device)

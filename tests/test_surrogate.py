@@ -250,3 +250,37 @@ def test_field_surrogate_interpolates_latents_and_reconstructs_the_profile():
     at = s.predict(torch.from_numpy(s._grid(beta)).cuda(), index_set=[b for b in s.index_set]).cpu().numpy().T
     full_rows = s.values[beta]
     assert np.max(np.abs(at - full_rows) / (np.abs(full_rows).max(axis=0) + 1e-300)) < 1e-9
+
+
+@pytest.mark.gpu
+def test_field_surrogate_with_more_latents_than_the_fused_launch_keeps():
+    """A compression map of rank 10 (> PEM_FUSED_LATENT_MAX_RANK = 8): the node values come from run() + compress() over a stored
+    profile instead of the fused launch, and everything downstream (13 outputs per node, predict, reconstruction) is unchanged."""
+    import torch
+    from hallthrusterpem_amd import _lib
+    from hallthrusterpem_amd.batch import CoupledBatch
+    from hallthrusterpem_amd.compression import SVDCompression
+    from oracle import surrogate_np as snp
+    rng = np.random.default_rng(2)
+    probe = SparseGridSurrogate(VARIED, FIXED, qoi=('V_cc', 'div_angle', 'T_c'))
+    t0 = rng.uniform(-1, 1, (len(VARIED), 400))
+    x = {k: np.full(400, v) for k, v in FIXED.items()}
+    x.update(probe.to_physical(t0))
+    b = CoupledBatch(400, profile=True)
+    b.set_inputs(x)
+    b.run()
+    torch.cuda.synchronize()
+    comp = SVDCompression(norm='log10', rank=10).fit(b.j_ion)
+    assert comp.rank == 10 > _lib.FUSED_LATENT_MAX_RANK
+    s = SparseGridSurrogate(VARIED, FIXED, qoi=('V_cc', 'div_angle', 'T_c', 'j_ion'), compression=comp)
+    assert s.n_out == 13
+    y = s._true_outputs(x, 400)
+    assert torch.equal(y[:, 3:], comp.compress(b.j_ion)) and torch.equal(y[:, 0], b.qoi[0])
+    s.refine(max_iter=12, num_refine=200, seed=0)
+    t = rng.uniform(-1, 1, (len(VARIED), 500))
+    td = torch.from_numpy(t).cuda()
+    pred = s.predict(td)
+    want = snp.predict(s.index_set, s.combination_coefficients(s.index_set), s.values, t)
+    assert np.max(np.abs(pred.cpu().numpy() - want) / np.abs(want).max(axis=1, keepdims=True)) < 1e-12
+    both = s.predict_fields(td)
+    assert torch.allclose(both['j_ion'], comp.reconstruct(pred[3:].T.contiguous()), rtol=1e-11, atol=0.0)

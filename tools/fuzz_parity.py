@@ -86,6 +86,8 @@ def main():
     ap.add_argument('--first-seed', type=int, default=0, help='first seed of the range (campaigns longer than one GPU call are run in pieces)')
     ap.add_argument('--seed-list', type=int, nargs='*', default=[], help='further seeds (e.g. the ones earlier campaigns failed on)')
     ap.add_argument('--n', type=int, default=20_000)
+    ap.add_argument('--time-budget', type=float, default=0.0, metavar='SECONDS',
+                    help='stop starting new seeds after this long and summarise the seeds that ran (a GPU call has a hard limit; 0 = none)')
     ap.add_argument('--many-radii-samples', type=int, default=3000, help='samples per seed that also go through 9 / 17 / 40 sweep radii')
     ap.add_argument('--dump', default='', help='write the worst sample of every quantity (inputs, got, want) to this .npz')
     ap.add_argument('--priors', type=int, default=0, metavar='BATCHES',
@@ -143,8 +145,15 @@ def main():
         note(f'{tag}.div_angle', d['err_div'], **d)
         note(f'{tag}.T_c', d['err_tc'], **d)
 
-    seeds = list(range(args.first_seed, args.seeds)) + [s_ for s_ in args.seed_list if not args.first_seed <= s_ < args.seeds]
+    import time
+    t_start = time.perf_counter()
+    seeds = [s_ for s_ in args.seed_list if not args.first_seed <= s_ < args.seeds] + list(range(args.first_seed, args.seeds))
+    ran = []
     for it, seed in enumerate(seeds):
+        if args.time_budget and time.perf_counter() - t_start > args.time_budget:
+            print(f'time budget of {args.time_budget:.0f} s reached before seed {seed}: {len(seeds) - it} seeds not run', flush=True)
+            break
+        ran.append(seed)
         seed_now[0] = seed
         if it % 25 == 0:
             print(f'seed {seed} ({it} / {len(seeds)})', flush=True)      # a long campaign must not look hung
@@ -227,7 +236,9 @@ def main():
                 bR = pr.plume_bounds(tR, ps['I_B0'])
             g = current_density(ps, sweep_radius=np.array(radii))
             plume_check(f'plume[R={R}]', g, w, bR, seed, inputs=ps)
-    print(f'{len(seeds)} seeds x {args.n} wild samples (seeds {args.first_seed}..{args.seeds - 1}' + (f' + {args.seed_list}' if args.seed_list else '') + '):')
+    in_range = [s_ for s_ in ran if args.first_seed <= s_ < args.seeds]
+    print(f'{len(ran)} seeds x {args.n} wild samples (seeds {in_range[0] if in_range else "-"}..{in_range[-1] if in_range else "-"}'
+          + (f' + {[s_ for s_ in ran if s_ not in in_range]}' if len(in_range) < len(ran) else '') + '):')
     print('NaN / inf / invalid patterns identical everywhere; worst errors (1e-10 = at the bound) and the cancellation they met:')
     for key, v in sorted(worst.items()):
         e = extra[key]
