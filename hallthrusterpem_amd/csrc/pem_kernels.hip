@@ -1186,6 +1186,9 @@ __global__ __launch_bounds__(BLOCK) void plume_radii_kernel(PlumeIO io, RadiiArg
 // profiles/radii_mid_r03.txt).  So: the doubles up to the next line boundary as one partial instruction of 8-byte stores, then
 // 16 bytes per lane, 1 KiB per instruction, line-aligned; an odd double left at the end goes out alone.
 __device__ __forceinline__ void stream_run(const double* from, double* dst, int len, int lane) {
+#if defined(PEM_RMID_EXP) && PEM_RMID_EXP == 1     // experiment: the phases without their stores (tools/rmid_ab_probe.py)
+    if (len >= 0) return;
+#endif
     int head = (int)((0 - (reinterpret_cast<uintptr_t>(dst) >> 3)) & 15);
     head = head < len ? head : len;
     if (lane < head) __builtin_nontemporal_store(from[lane], dst + lane);
@@ -1199,7 +1202,13 @@ __device__ __forceinline__ void stream_run(const double* from, double* dst, int 
 constexpr int RADII_SMALL = 8;                  // up to here: the recurrence kernel with the radii in registers (plume_rfew_kernel)
 constexpr int RMID_MAX = 64;
 constexpr int RMID_G_MAX = 5;                   // samples in flight per wave the staged kernel is instantiated for (R >= 11)
-constexpr int RMID_TILE = 1024;                 // doubles of staged rows per wave
+// doubles of staged rows per wave: 10 KB -- with the Gaussians' 1.5 KB per sample what three workgroups per CU leave each other.
+// (Round 4, profiles/radii_mid_r04.txt: 512 / 768 / 1024 / 1280 doubles give 3.08 / 3.38 / 3.58 / 3.82 TB/s at 17 radii, 3.36 / 3.55 /
+// 3.73 / 3.85 at 25; radius counts whose rows are whole lines -- 32, 64 -- do not care.)
+#ifndef PEM_RMID_TILE_DOUBLES
+#define PEM_RMID_TILE_DOUBLES 1280
+#endif
+constexpr int RMID_TILE = PEM_RMID_TILE_DOUBLES;
 struct RadiiMidArg {
     double r[RMID_MAX];
 };
@@ -1324,9 +1333,14 @@ void plume_rmid_kernel(PlumeIO io, RadiiMidArg radii_arg, int R, int ts) {
                     // where this pair's run starts in j_ion: the LDS copy gets the same parity
                     const double* gdst = io.j_ion + ((size_t)g[p] * NANG + k0) * R;
                     double* run = tile + grp[p] * RS + (int)((reinterpret_cast<uintptr_t>(gdst) >> 3) & 1);
+#if defined(PEM_RMID_EXP) && PEM_RMID_EXP == 2     // experiment: the stores without the rows' arithmetic (one row computed per chunk)
+                    if (on[p]) {
+                        for (int kk = 0; kk < (rows > 1 ? 1 : rows); ++kk) {
+#else
                     if (on[p]) {
 #pragma unroll 4
                         for (int kk = 0; kk < rows; ++kk) {
+#endif
                             const int k = k0 + kk;
                             const double2 ee = E[grp[p] * RMID_ES + k];
                             const double f = b1[p] * ee.x + b2[p] * ee.y;      // j_beam + j_scat
@@ -2268,6 +2282,8 @@ int pem_plume_f64_dev(size_t n, int n_radii, const double* radii, double torr2pa
         const size_t lds = (size_t)(BLOCK / WAVE) * rmid_wave_doubles<S_>() * 8;                                    \
         size_t per_cu = (160 * 1024) / lds;                                                                         \
         if (per_cu > (size_t)rmid_waves_per_simd<S_, P_>()) per_cu = rmid_waves_per_simd<S_, P_>();                 \
+        static pem::LdsAttrOnce attr;                          /* (four and five samples per wave: more than 64 KB) */ \
+        HIP_TRY(attr.ensure(reinterpret_cast<const void*>(plume_rmid_kernel<S_, P_>)));                             \
         blocks = balanced_grid(blocks, (size_t)cus * per_cu);                                                       \
         hipLaunchKernelGGL((plume_rmid_kernel<S_, P_>), dim3((unsigned)blocks), dim3(BLOCK), lds, st, io, ra, n_radii, ts); \
     } while (0)
