@@ -71,9 +71,11 @@ SIGNATURES = {
     'pem_quantiles_strided_f64_dev': (C.c_int, [_sz, C.c_int, _dp, _sz, _sz, C.c_int, _dp, _dp, _dp, _dp, _dp]),
     'pem_quantiles_last_path': (C.c_int, []),
     'pem_coupled_mc_stats_f64_dev': (C.c_int, [_sz, C.c_uint64, C.c_uint64, C.c_uint32, _dp, _dp, _dp, C.c_double, C.c_double, _dp, _sz,
-                                               _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp, _dp,
+                                               _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp,
                                                C.c_int, C.c_int, C.c_double, _dp, _dp, _dp, _dp]),
     'pem_row_masks_f64_dev': (C.c_int, [_sz, C.c_int, _dp, _sz, _dp, _dp, _dp, _dp, _dp]),
+    'pem_campaign_masks_f64_dev': (C.c_int, [_sz, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_double, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp,
+                                             C.c_int, _dp]),
     'pem_sobol_partial_f64_dev': (C.c_int, [_sz, C.c_int, _sz, _dp, _dp, _dp, _dp, C.c_int, _dp]),
     'pem_coupled_f32_dev': (C.c_int, [_sz, C.c_float, C.c_float, _dp, _sz, _dp, _sz, _dp, _dp]),
     'pem_saltelli_f32_dev': (C.c_int, [_sz, C.c_uint64, C.c_uint64, C.c_uint32, _dp, _dp, _dp, C.c_int, _dp, C.c_float, C.c_float, _dp, _dp, C.c_int, _dp]),

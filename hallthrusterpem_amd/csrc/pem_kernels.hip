@@ -44,7 +44,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <future>
 #include <mutex>
+#include <string>
+#include <thread>
 #include <type_traits>
 
 #include "pem_common.h"
@@ -2482,9 +2485,57 @@ extern "C" {
 
 // ---- coupled, fused Monte-Carlo with the percentiles of the profile counted on the way (round 4) --------------------------------
 namespace {
+// The scalar QoIs' percentiles of a campaign, selected on a second host thread and stream while the calling thread takes the profile's
+// records through their passes (csrc/pem_quantile.hip keeps a second set of buffers for it): the worker waits -- on the host for
+// `go`, on the device for `ev` -- until the launch that writes the scalars is under way.
+struct ScalarJob {
+    std::promise<int> go;                      // 1: `ev` marks the launch that writes the scalars; 0: give up (an error on the calling thread)
+    bool signalled = false;
+    hipEvent_t ev = nullptr;
+    std::thread worker;
+    int rc = PEM_OK;
+    std::string error;
+    void signal(int v) {
+        if (!signalled) {
+            signalled = true;
+            go.set_value(v);
+        }
+    }
+    // after the launch that (re)writes the scalars has been enqueued on `st`
+    int launched(hipStream_t st) {
+        if (signalled) return PEM_OK;
+        HIP_TRY(hipEventRecord(ev, st));
+        signal(1);
+        return PEM_OK;
+    }
+    int join() {
+        signal(0);
+        if (worker.joinable()) worker.join();
+        if (ev) (void)hipEventDestroy(ev);
+        ev = nullptr;
+        return rc;
+    }
+    ~ScalarJob() { (void)join(); }
+};
+
+// a stream of the library's own per device (created once)
+int side_stream(hipStream_t* out) {
+    static std::mutex mu;
+    static hipStream_t streams[64] = {};
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(PEM_ERR_INVALID_ARG, "device index out of range");
+    std::lock_guard<std::mutex> lock(mu);
+    // (a higher stream priority for the side work was measured and changes nothing: 3.85-3.92 ms per 1e7-sample campaign either way)
+    if (!streams[dev]) HIP_TRY(hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking));
+    *out = streams[dev];
+    return PEM_OK;
+}
+
 struct McProducer : pem::FusedProducer {
     pem::McLaunch a;
     bool store_profile;
+    ScalarJob* job = nullptr;
     int pilot(size_t rows, double* dst, hipStream_t st) override {
         pem::McLaunch p = a;                       // samples 0 .. rows-1 of the same design; their profile rows go to dst
         p.n = rows;
@@ -2492,16 +2543,19 @@ struct McProducer : pem::FusedProducer {
         return pem::launch_coupled_mc(p, st);
     }
     int waves(int nq, unsigned* w) override { return pem::coupled_count_waves(a.n, nq, store_profile, w); }
-    int count(const pem::CountIO& io, hipStream_t st) override { return pem::launch_coupled_mc_count(a, io, store_profile, st); }
+    int count(const pem::CountIO& io, hipStream_t st) override {
+        if (int rc = pem::launch_coupled_mc_count(a, io, store_profile, st)) return rc;
+        return job ? job->launched(st) : PEM_OK;  // (the scalars' selection may start behind this launch)
+    }
 };
 }  // namespace
 
 int pem_coupled_mc_stats_f64_dev(size_t n, uint64_t first_index, uint64_t seed, uint32_t stream_id, const int32_t* kind, const double* a,
                                  const double* b, double torr2pa, double radius, double* x_out, size_t ld, double* V_cc, double* I_B0,
                                  double* T, double* j_ion, double* pilot_rows, double* div_angle, double* T_c, uint8_t* invalid, int nq,
-                                 const uint64_t* rank_prev, const uint64_t* rank_next, const double* gamma, double* q_out, int* fused_ok,
-                                 int q25, int q75, double iqr_factor, uint8_t* row_certain, uint8_t* row_uncertain, int* premask_ok,
-                                 pem_stream_t stream) {
+                                 const uint64_t* rank_prev, const uint64_t* rank_next, const double* gamma, double* q_out, double* q_scalars,
+                                 int* fused_ok, int q25, int q75, double iqr_factor, uint8_t* row_certain, uint8_t* row_uncertain,
+                                 int* premask_ok, pem_stream_t stream) {
     if (!kind || !a || !b || !V_cc || !div_angle || !T_c || !rank_prev || !rank_next || !gamma || !q_out || !fused_ok)
         return fail(PEM_ERR_INVALID_ARG, "pem_coupled_mc_stats: NULL array");
     if (!j_ion && !pilot_rows) return fail(PEM_ERR_INVALID_ARG, "pem_coupled_mc_stats: without a profile array, room for the pilot rows is needed");
@@ -2510,8 +2564,35 @@ int pem_coupled_mc_stats_f64_dev(size_t n, uint64_t first_index, uint64_t seed, 
     if (x_out && ld < n) return fail(PEM_ERR_INVALID_ARG, "pem_coupled_mc_stats: leading dimension smaller than n");
     if (nq < 1 || nq > PEM_QUANTILE_MAX_Q) return fail(PEM_ERR_INVALID_ARG, "pem_coupled_mc_stats: 1 <= nq <= %d", PEM_QUANTILE_MAX_Q);
     if (n < PEM_MC_STATS_MIN_N) return fail(PEM_ERR_INVALID_ARG, "pem_coupled_mc_stats: at least %d samples", PEM_MC_STATS_MIN_N);
+    // q_scalars: V_cc, div_angle, T_c must then be rows 0, 1, 2 of one [3][row stride >= n] array (the reduced-QoI tensor)
+    const ptrdiff_t qstride = div_angle - V_cc;
+    if (q_scalars && (qstride < (ptrdiff_t)n || T_c - div_angle != qstride))
+        return fail(PEM_ERR_INVALID_ARG, "pem_coupled_mc_stats: q_scalars needs V_cc, div_angle, T_c as equally spaced rows of one array");
     if (int rc = check_device()) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ScalarJob job;
     McProducer prod;
+    if (q_scalars) {
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        hipStream_t side = nullptr;
+        if (int rc = side_stream(&side)) return rc;
+        HIP_TRY(hipEventCreateWithFlags(&job.ev, hipEventDisableTiming));
+        std::future<int> go = job.go.get_future();
+        job.worker = std::thread([&job, dev, side, n, nq, V_cc, qstride, rank_prev, rank_next, gamma, q_scalars, go = std::move(go)]() mutable {
+            if (go.get() != 1) return;
+            hipError_t e = hipSetDevice(dev);
+            if (e == hipSuccess) e = hipStreamWaitEvent(side, job.ev, 0);
+            if (e != hipSuccess) {
+                job.rc = PEM_ERR_HIP;
+                job.error = std::string("pem_coupled_mc_stats (scalar selection): ") + hipGetErrorString(e);
+                return;
+            }
+            job.rc = pem::quantiles_side(n, 3, V_cc, 1, (size_t)qstride, nq, rank_prev, rank_next, gamma, q_scalars, side);
+            if (job.rc != PEM_OK) job.error = pem_last_error();      // (the message lives in this thread's buffer)
+        });
+        prod.job = &job;
+    }
     prod.a.n = n;
     prod.a.first_index = first_index;
     prod.a.seed = seed;
@@ -2543,15 +2624,24 @@ int pem_coupled_mc_stats_f64_dev(size_t n, uint64_t first_index, uint64_t seed, 
     if (premask_ok) *premask_ok = 0;
     *fused_ok = 0;
     // with a profile array the pilot rows are its own first rows (the counting launch writes the same values there again)
-    if (int rc = pem::quantiles_fused(n, NANG, nq, rank_prev, rank_next, gamma, j_ion ? j_ion : pilot_rows, prod, q_out, fused_ok,
-                                      static_cast<hipStream_t>(stream)))
-        return rc;
+    if (int rc = pem::quantiles_fused(n, NANG, nq, rank_prev, rank_next, gamma, j_ion ? j_ion : pilot_rows, prod, q_out, fused_ok, st))
+        return rc;                                 // (~ScalarJob tells the worker to give up and joins it)
     if (premask_ok) *premask_ok = (*fused_ok && prod.pm_done) ? 1 : 0;
     if (!*fused_ok) {
         // declined -- possibly before the counting launch, with nothing but the pilot's samples evaluated: the plain launch makes
-        // every output complete (a rare path: 1.5 ms per 1e7 samples where the counting launch had already run)
-        if (int rc = pem::launch_coupled_mc(prod.a, static_cast<hipStream_t>(stream))) return rc;
-        HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+        // every output complete (a rare path: 1.5 ms per 1e7 samples where the counting launch had already run).  A scalar selection
+        // that started behind the counting launch is let finish first (the plain launch writes the same scalars again).
+        if (q_scalars && job.signalled) {
+            if (int rc = job.join()) return fail(rc, "%s", job.error.c_str());
+        }
+        if (int rc = pem::launch_coupled_mc(prod.a, st)) return rc;
+        if (q_scalars) {
+            if (int rc = job.launched(st)) return rc;
+        }
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    if (q_scalars) {                               // (signalled by now on every path that comes here)
+        if (int rc = job.join()) return fail(rc, "%s", job.error.c_str());
     }
     return PEM_OK;
 }

@@ -102,6 +102,79 @@ __global__ __launch_bounds__(MBLOCK) void row_masks_wide_kernel(long long n, int
 
 }  // namespace
 
+namespace {
+
+// The masks of a campaign's scalar outputs and the verdict of the profile's premask counts, one thread per sample
+// (pem_campaign_masks_f64_dev): what drivers.forward_uq_statistics did in some twenty elementwise torch launches over n.
+constexpr int CM_MAX_VARS = 8;
+struct CampaignVars {
+    const double* v[CM_MAX_VARS];
+};
+__global__ __launch_bounds__(MBLOCK) void campaign_masks_kernel(long long n, int nvar, CampaignVars vars, const double* __restrict__ q, int q_ld,
+                                                                int row25, int row75, double factor, uint8_t* __restrict__ nan_out,
+                                                                uint8_t* __restrict__ outl_out, const uint8_t* __restrict__ certain,
+                                                                const uint8_t* __restrict__ uncertain, int thresh,
+                                                                long long* __restrict__ open_rows, int* __restrict__ open_count, int cap) {
+    // gen_data.py:163-166: iqr = p75 - p25; the bounds p25 - f iqr and p75 + f iqr, every operation rounded on its own as numpy does
+    double lo[CM_MAX_VARS], hi[CM_MAX_VARS];
+#pragma unroll
+    for (int k = 0; k < CM_MAX_VARS; ++k) {
+        const double p25 = k < nvar ? q[(size_t)row25 * q_ld + k] : 0.0, p75 = k < nvar ? q[(size_t)row75 * q_ld + k] : 0.0;
+        const double iqr = __dsub_rn(p75, p25);
+        lo[k] = __dsub_rn(p25, __dmul_rn(factor, iqr));
+        hi[k] = __dadd_rn(p75, __dmul_rn(factor, iqr));
+    }
+    const long long stride = (long long)gridDim.x * MBLOCK;
+    for (long long i = (long long)blockIdx.x * MBLOCK + threadIdx.x; i < n; i += stride) {
+#pragma unroll
+        for (int k = 0; k < CM_MAX_VARS; ++k) {
+            if (k < nvar) {
+                const double x = __builtin_nontemporal_load(vars.v[k] + i);
+                nan_out[(size_t)k * n + i] = (uint8_t)(x != x);                       // np.isnan
+                outl_out[(size_t)k * n + i] = (uint8_t)((x < lo[k]) | (x > hi[k]));   // one entry per sample: "any entry outside" (a NaN compares false)
+            }
+        }
+        if (certain) {
+            const int c = certain[i], u = uncertain[i];
+            const bool out = c > thresh;
+            nan_out[(size_t)nvar * n + i] = 0;                                    // (a non-finite profile value makes the selection decline)
+            outl_out[(size_t)nvar * n + i] = (uint8_t)out;
+            if (!out && c + u > thresh) {                                         // the uncertain values could change the verdict: the caller looks again
+                const int at = atomicAdd(open_count, 1);
+                if (at < cap) open_rows[at] = i;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int pem_campaign_masks_f64_dev(size_t n, int nvar, const double* const* vars, const double* q, int q_ld, int row25, int row75,
+                                          double iqr_factor, uint8_t* nan_out,
+                                          uint8_t* outl_out, const uint8_t* row_certain, const uint8_t* row_uncertain, int thresh,
+                                          int64_t* open_rows, int32_t* open_count, int cap, pem_stream_t stream) {
+    if (nvar < 0 || nvar > CM_MAX_VARS) return pem::fail(PEM_ERR_INVALID_ARG, "pem_campaign_masks: 0 <= nvar <= %d", CM_MAX_VARS);
+    if (!nan_out || !outl_out || (nvar && (!vars || !q))) return pem::fail(PEM_ERR_INVALID_ARG, "pem_campaign_masks: NULL array");
+    if (nvar && (q_ld < nvar || row25 < 0 || row75 < 0)) return pem::fail(PEM_ERR_INVALID_ARG, "pem_campaign_masks: rows of q hold nvar values, q_ld apart");
+    if ((row_certain != nullptr) != (row_uncertain != nullptr) || (row_certain && (!open_rows || !open_count || cap < 0)))
+        return pem::fail(PEM_ERR_INVALID_ARG, "pem_campaign_masks: the premask counts come with open_rows and open_count");
+    if (n == 0) return PEM_OK;
+    if (int rc = pem::check_device()) return rc;
+    CampaignVars cv{};
+    for (int k = 0; k < nvar; ++k) {
+        if (!vars[k]) return pem::fail(PEM_ERR_INVALID_ARG, "pem_campaign_masks: NULL variable");
+        cv.v[k] = vars[k];
+    }
+    int cus = 0;
+    HIP_TRY(pem::device_cus(&cus));
+    long long blocks = ((long long)n + MBLOCK - 1) / MBLOCK;
+    if (blocks > (long long)cus * 8) blocks = (long long)cus * 8;
+    hipLaunchKernelGGL(campaign_masks_kernel, dim3((unsigned)blocks), dim3(MBLOCK), 0, static_cast<hipStream_t>(stream), (long long)n, nvar, cv, q, q_ld,
+                       row25, row75, iqr_factor, nan_out, outl_out, row_certain, row_uncertain, thresh, (long long*)open_rows, (int*)open_count, cap);
+    HIP_TRY(hipGetLastError());
+    return PEM_OK;
+}
+
 extern "C" int pem_row_masks_f64_dev(size_t n, int m, const double* data, size_t ld, const double* lo, const double* hi, uint8_t* nan_out,
                                      int32_t* outside_out, pem_stream_t stream) {
     if (m < 1 || m > PEM_ROW_MASKS_MAX_M) return pem::fail(PEM_ERR_INVALID_ARG, "pem_row_masks: 1 <= m <= %d entries per sample", PEM_ROW_MASKS_MAX_M);

@@ -88,5 +88,10 @@ struct FusedProducer {
 __attribute__((visibility("hidden"))) int quantiles_fused(size_t n, int m, int nq, const uint64_t* rank_prev, const uint64_t* rank_next,
                                                           const double* gamma, double* pilot_rows, FusedProducer& prod, double* out,
                                                           int* fused_ok, hipStream_t st);
+// the plain selection (pem_quantiles_strided_f64_dev) on the SECOND workspace of the library: may run on another host thread and stream
+// while quantiles_fused is under way (the scalar QoIs of a campaign, selected while the profile's records are being sorted)
+__attribute__((visibility("hidden"))) int quantiles_side(size_t n, int m, const double* data, size_t ld, size_t cs, int nq,
+                                                         const uint64_t* rank_prev, const uint64_t* rank_next, const double* gamma, double* out,
+                                                         hipStream_t st);
 
 }  // namespace pem

@@ -67,6 +67,30 @@ __device__ __forceinline__ int bin_of(u64 k, const Scale& s, unsigned& frac) {
     return (int)(p >> 32);
 }
 __device__ __forceinline__ int subbin_of(unsigned frac, int bins2) { return (int)__umulhi(frac, (unsigned)bins2); }
+// The keys of bin b (bins2 = 1, g = b) or of sub-bin (b, sb) (g = b bins2 + sb) of a column's binning, [klo, khi], by bisection on
+// the monotone map d -> bin(d) bins2 + sub-bin(d).  The streaming passes test a value's HIGH word against these ranges (two 32-bit
+// instructions per wanted bin) before they bin it in full: a value outside every wanted bin -- all but a few per cent -- costs
+// neither the 64-bit subtraction nor the quarter-rate multiply of bin_of.  An empty bin comes out as klo > khi.
+__device__ __forceinline__ void keys_of_bin(const Scale& sc, u64 kmax, int bins2, long long g, u64& klo, u64& khi) {
+    const u64 D = kmax >= sc.lo ? (kmax - sc.lo) >> sc.shift : 0;
+    auto first = [&](long long G) {
+        u64 lo = 0, hi = D + 1;
+        while (lo < hi) {
+            const u64 mid = (lo + hi) >> 1, prod = mid * sc.mult;
+            const long long gd = (long long)(prod >> 32) * bins2 + (bins2 > 1 ? (long long)__umulhi((unsigned)prod, (unsigned)bins2) : 0);
+            if (gd >= G) hi = mid;
+            else lo = mid + 1;
+        }
+        return lo;
+    };
+    const u64 d0 = first(g), d1 = first(g + 1);
+    klo = sc.lo + (d0 << sc.shift);
+    khi = d1 > D ? kmax : sc.lo + (d1 << sc.shift) - 1;
+    if (d0 > D || d0 >= d1) {
+        klo = ~0ull;
+        khi = 0ull;
+    }
+}
 // the select kernel's own refinement (rare, over short lists): bins in double arithmetic over any key range
 __device__ __forceinline__ int bin_of_d(u64 k, u64 lo, double inv, int bins) {
     const int b = (int)((double)(k - lo) * inv);
@@ -389,21 +413,36 @@ __global__ __launch_bounds__(64) void decide2_kernel(int nt, const unsigned* __r
 // start in the candidate buffer (a scan over the columns in LDS)
 __global__ __launch_bounds__(64 * MAX_NC) void layout_kernel(int m, int nt, Target* __restrict__ tg, u64* __restrict__ total) {
     __shared__ u64 start[64 * MAX_NC + 1];
+    constexpr int NTMAX = 2 * PEM_QUANTILE_MAX_Q;
     const int c = threadIdx.x;
+    // (the column's targets are read ONCE, side by side, into registers: walked through global memory -- a dependent load per
+    // comparison, ~50 per column -- this one workgroup took 50 us of a campaign's critical path)
+    int bin1[NTMAX], bin2[NTMAX], owner[NTMAX];
+    bool done[NTMAX];
+    u64 count[NTMAX];
     u64 mine = 0;
     if (c < m) {
-        for (int t = 0; t < nt; ++t) {
-            Target& T = tg[c * nt + t];
-            if (T.done) continue;
-            T.owner = t;
-            for (int u = 0; u < t; ++u) {
-                const Target& U = tg[c * nt + u];
-                if (!U.done && U.bin1 == T.bin1 && U.bin2 == T.bin2) {
-                    T.owner = U.owner;
-                    break;
+#pragma unroll
+        for (int t = 0; t < NTMAX; ++t) {
+            const Target& T = tg[c * nt + (t < nt ? t : 0)];
+            done[t] = t >= nt || T.done != 0;
+            bin1[t] = T.bin1;
+            bin2[t] = T.bin2;
+            count[t] = T.count;
+            owner[t] = t;
+        }
+#pragma unroll
+        for (int t = 0; t < NTMAX; ++t) {
+            if (done[t]) continue;
+            bool found = false;
+#pragma unroll
+            for (int u = 0; u < NTMAX; ++u) {
+                if (u < t && !found && !done[u] && bin1[u] == bin1[t] && bin2[u] == bin2[t]) {
+                    owner[t] = owner[u];
+                    found = true;
                 }
             }
-            if (T.owner == t) mine += T.count;
+            if (owner[t] == t) mine += count[t];
         }
     }
     start[c + 1] = mine;
@@ -416,15 +455,21 @@ __global__ __launch_bounds__(64 * MAX_NC) void layout_kernel(int m, int nt, Targ
     __syncthreads();
     if (c < m) {
         u64 off = start[c];
-        for (int t = 0; t < nt; ++t) {
-            Target& T = tg[c * nt + t];
-            if (T.done) continue;
-            if (T.owner == t) {
-                T.offset = off;
-                off += T.count;
+        u64 offs[NTMAX];
+#pragma unroll
+        for (int t = 0; t < NTMAX; ++t) {
+            offs[t] = 0;
+            if (done[t]) continue;
+            if (owner[t] == t) {
+                offs[t] = off;
+                off += count[t];
             } else {
-                T.offset = tg[c * nt + T.owner].offset;
+#pragma unroll
+                for (int u = 0; u < NTMAX; ++u)
+                    if (u < t && u == owner[t]) offs[t] = offs[u];
             }
+            tg[c * nt + t].owner = owner[t];
+            tg[c * nt + t].offset = offs[t];
         }
     }
 }
@@ -651,6 +696,26 @@ using pem::Bracket;     // per (column, quantile): the keys lo .. hi, binned on 
 // high word EQUALS that of lo or hi (one value in 1e5) is compared in full.  A bracket narrower than `bins` high words -- a
 // column with a relative spread below 1e-5 -- puts several sub-bins' worth of values into one list; select_from narrows such a
 // list by histograms of its own, as it does for ties.
+// The fused form's pilot does not need the subsample's order statistics themselves: any key at or below x_(r_lo) will do as a
+// bracket's lower end, any key at or above x_(r_hi) as its upper end (the counts of the full run prove the bracket, whatever it
+// is).  So its run stops after the second histogram: a lower end becomes the FIRST key of the sub-bin that holds its rank, an
+// upper end the LAST key of its sub-bin -- no candidate lists, no copy pass over the subsample, no sort (a sub-bin holds a few
+// dozen of the subsample's ~4000 values between the ends).  Targets 2q / 2q + 1 are a bracket's lower / upper end.
+__global__ __launch_bounds__(64) void pilot_edges_kernel(int total, int nt, int bins2, const Column* __restrict__ col, Target* __restrict__ tg) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    Target T = tg[i];
+    if (T.done) return;
+    const Column C = col[i / nt];
+    Scale sc;
+    sc.lo = C.kmin;
+    sc.mult = C.mult;
+    sc.shift = C.shift;
+    u64 klo, khi;
+    keys_of_bin(sc, C.kmax, bins2, (long long)T.bin1 * bins2 + T.bin2, klo, khi);
+    tg[i].answer = ((i % nt) & 1) ? khi : klo;
+}
+
 struct PilotEnds {       // a bracket end that would lie outside the subsample is open: the smallest / largest key
     int open_lo[PEM_QUANTILE_MAX_Q], open_hi[PEM_QUANTILE_MAX_Q];
 };
@@ -941,21 +1006,10 @@ __global__ void premask_bounds_kernel(int m, int nq, const Bracket* __restrict__
     thr[c] = make_uint4(key_high(lo_min), key_high(lo_max), key_high(hi_min), key_high(hi_max));
 }
 
-// the records the producer wrote are the values the record histogram counted (one workgroup)
-__global__ __launch_bounds__(QBLOCK) void record_total_check_kernel(const unsigned* __restrict__ rec_count, unsigned cap, unsigned waves,
-                                                                     const unsigned* __restrict__ hist, int cells, int* __restrict__ inconsistent,
-                                                                     const int* __restrict__ prod_flags) {
-    __shared__ u64 s_rec, s_hist;
-    if (threadIdx.x == 0) s_rec = s_hist = 0;
-    __syncthreads();
-    u64 r = 0, h = 0;
-    for (unsigned w = threadIdx.x; w < waves; w += QBLOCK) r += rec_count[w] < cap ? rec_count[w] : cap;
-    for (int i = threadIdx.x; i < cells; i += QBLOCK) h += hist[i];
-    atomicAdd(&s_rec, r);
-    atomicAdd(&s_hist, h);
-    __syncthreads();
+// the records the producer wrote are the values the record histogram counted (sums: record_reduce_kernel's)
+__global__ void record_total_check_kernel(const u64* __restrict__ sums, int* __restrict__ inconsistent, const int* __restrict__ prod_flags) {
     // (a run the producer flagged -- overflow, a non-finite value -- is discarded anyway, and its records need not add up)
-    if (threadIdx.x == 0 && s_rec != s_hist && !prod_flags[0] && !prod_flags[1]) atomicExch(inconsistent, -1);
+    if (threadIdx.x == 0 && sums[0] != sums[1] && !prod_flags[0] && !prod_flags[1]) atomicExch(inconsistent, -1);
 }
 
 constexpr int REC_LISTS_MAX = 64 * 2 * PEM_QUANTILE_MAX_Q;     // (column, quantile) pairs the record kernels keep a table of (m <= 128)
@@ -987,29 +1041,32 @@ __device__ __forceinline__ int record_list(const uint4* __restrict__ s_br, const
 
 constexpr int REC_UNROLL = 4;   // records a thread has in flight
 
+// (the record passes run one workgroup per CU -- its histogram takes the CU's LDS -- so the workgroup is 1024 threads: with 256 the
+// passes were latency-bound at 2.5 TB/s over the records)
+constexpr int RBLOCK = 1024;
 template <int NQ>
-__global__ __launch_bounds__(QBLOCK) void record_hist_kernel(const pem::Record* __restrict__ rec, const unsigned* __restrict__ rec_count, unsigned cap,
+__global__ __launch_bounds__(RBLOCK) void record_hist_kernel(const pem::Record* __restrict__ rec, const unsigned* __restrict__ rec_count, unsigned cap,
                                                               unsigned waves, const Bracket* __restrict__ br, int lists, int bins,
                                                               unsigned* __restrict__ hist) {
     extern __shared__ unsigned lds_hist[];                      // [lists][bins]
     __shared__ uint4 s_br[REC_LISTS_MAX];                       // {loh, words, mult, -}
-    for (int i = threadIdx.x; i < lists * bins; i += QBLOCK) lds_hist[i] = 0;
-    for (int i = threadIdx.x; i < lists; i += QBLOCK) s_br[i] = make_uint4(br[i].loh, br[i].words, br[i].mult, 0u);
+    for (int i = threadIdx.x; i < lists * bins; i += RBLOCK) lds_hist[i] = 0;
+    for (int i = threadIdx.x; i < lists; i += RBLOCK) s_br[i] = make_uint4(br[i].loh, br[i].words, br[i].mult, 0u);
     __syncthreads();
     for (unsigned w = blockIdx.x; w < waves; w += gridDim.x) {
         const unsigned cnt = rec_count[w] < cap ? rec_count[w] : cap;
         const pem::Record* r = rec + (size_t)w * cap;
-        for (unsigned i0 = threadIdx.x; i0 < cnt; i0 += QBLOCK * REC_UNROLL) {
+        for (unsigned i0 = threadIdx.x; i0 < cnt; i0 += RBLOCK * REC_UNROLL) {
             pem::Record e[REC_UNROLL];
 #pragma unroll
-            for (int u = 0; u < REC_UNROLL; ++u) e[u] = r[i0 + u * QBLOCK < cnt ? i0 + u * QBLOCK : i0];
+            for (int u = 0; u < REC_UNROLL; ++u) e[u] = r[i0 + u * RBLOCK < cnt ? i0 + u * RBLOCK : i0];
 #pragma unroll
             for (int u = 0; u < REC_UNROLL; ++u) {
                 unsigned t, mult;
                 bool none;
                 const int cq = record_list<NQ>(s_br, e[u], t, mult, none);
                 // (none: not a value of any bracket -- a NaN's bits; the producer has flagged the run)
-                if (!none && i0 + u * QBLOCK < cnt) atomicAdd(&lds_hist[cq * bins + (int)__umulhi(t, mult)], 1u);
+                if (!none && i0 + u * RBLOCK < cnt) atomicAdd(&lds_hist[cq * bins + (int)__umulhi(t, mult)], 1u);
             }
         }
     }
@@ -1017,15 +1074,48 @@ __global__ __launch_bounds__(QBLOCK) void record_hist_kernel(const pem::Record* 
     // the workgroup's own counts, whole (no atomics): summed over the workgroups by record_reduce_kernel, and read again -- per chosen
     // sub-bin -- by record_offsets_kernel, which gives every workgroup its own place in every list
     unsigned* mine = hist + (size_t)blockIdx.x * lists * bins;
-    for (int i = threadIdx.x; i < lists * bins; i += QBLOCK) mine[i] = lds_hist[i];
+    for (int i = threadIdx.x; i < lists * bins; i += RBLOCK) mine[i] = lds_hist[i];
 }
 
-__global__ __launch_bounds__(256) void record_reduce_kernel(const unsigned* __restrict__ part, int groups, int cells, unsigned* __restrict__ hist) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= cells) return;
+// 64 cells x 4 slices of the workgroups per block, eight loads in flight per thread (one thread per cell walking the 256 partial
+// histograms took 60-120 us of the critical path for 30 MB); the histogram's total and the producer's record count ride along
+// (sums[0], sums[1]: record_total_check_kernel compares them)
+__global__ __launch_bounds__(256) void record_reduce_kernel(const unsigned* __restrict__ part, int groups, int cells, unsigned* __restrict__ hist,
+                                                            const unsigned* __restrict__ rec_count, unsigned cap, unsigned waves,
+                                                            u64* __restrict__ sums) {
+    __shared__ unsigned s_part[4][64];
+    __shared__ u64 s_tot;
+    const int cx = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + cx;
+    if (threadIdx.x == 0) s_tot = 0;
     unsigned sum = 0;
-    for (int g = 0; g < groups; ++g) sum += part[(size_t)g * cells + i];
-    hist[i] = sum;
+    if (i < cells) {
+        int g = slice;
+        for (; g + 28 < groups; g += 32) {
+            unsigned v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(g + 4 * u) * cells + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sum += v[u];
+        }
+        for (; g < groups; g += 4) sum += part[(size_t)g * cells + i];
+    }
+    s_part[slice][cx] = sum;
+    __syncthreads();
+    if (slice == 0) {
+        const unsigned all = s_part[0][cx] + s_part[1][cx] + s_part[2][cx] + s_part[3][cx];
+        if (i < cells) {
+            hist[i] = all;
+            atomicAdd(&s_tot, (u64)all);
+        }
+    }
+    if (blockIdx.x == 0) {
+        u64 r = 0;
+        for (unsigned w = threadIdx.x; w < waves; w += 256) r += rec_count[w] < cap ? rec_count[w] : cap;
+        if (r) atomicAdd(&sums[1], r);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_tot) atomicAdd(&sums[0], s_tot);
 }
 
 // One wave per target that owns a list: where each workgroup of the copy pass appends its hits -- the exclusive prefix, over the
@@ -1054,7 +1144,7 @@ __global__ __launch_bounds__(64) void record_offsets_kernel(int nt, int bins, co
 }
 
 template <int NQ>
-__global__ __launch_bounds__(QBLOCK) void record_compact_kernel(const pem::Record* __restrict__ rec, const unsigned* __restrict__ rec_count, unsigned cap,
+__global__ __launch_bounds__(RBLOCK) void record_compact_kernel(const pem::Record* __restrict__ rec, const unsigned* __restrict__ rec_count, unsigned cap,
                                                                  unsigned waves, const Bracket* __restrict__ br, int lists, Target* __restrict__ tg,
                                                                  const unsigned* __restrict__ woff, u64* __restrict__ cand) {
     __shared__ uint4 s_br[REC_LISTS_MAX];                       // {loh, words, mult, -}
@@ -1062,7 +1152,7 @@ __global__ __launch_bounds__(QBLOCK) void record_compact_kernel(const pem::Recor
     __shared__ unsigned s_cur[2 * REC_LISTS_MAX];               // this workgroup's cursor in every target's list (from record_offsets_kernel)
     __shared__ u64 s_base[2 * REC_LISTS_MAX];                   // the lists' starts in `cand`
     const unsigned* my_off = woff + (size_t)blockIdx.x * 2 * lists;
-    for (int i = threadIdx.x; i < lists; i += QBLOCK) {
+    for (int i = threadIdx.x; i < lists; i += RBLOCK) {
         s_br[i] = make_uint4(br[i].loh, br[i].words, br[i].mult, 0u);
         const Target &T0 = tg[2 * i], &T1 = tg[2 * i + 1];     // targets 2q, 2q + 1 of column c sit at (c nq + q) 2
         s_bin[i] = make_int2((!T0.done && (T0.owner & 1) == 0) ? T0.bin2 : -1, (!T1.done && (T1.owner & 1) == 1) ? T1.bin2 : -1);
@@ -1076,16 +1166,16 @@ __global__ __launch_bounds__(QBLOCK) void record_compact_kernel(const pem::Recor
     for (unsigned w = blockIdx.x; w < waves; w += gridDim.x) {
         const unsigned cnt = rec_count[w] < cap ? rec_count[w] : cap;
         const pem::Record* r = rec + (size_t)w * cap;
-        for (unsigned i0 = threadIdx.x; i0 < cnt; i0 += QBLOCK * REC_UNROLL) {
+        for (unsigned i0 = threadIdx.x; i0 < cnt; i0 += RBLOCK * REC_UNROLL) {
             pem::Record e[REC_UNROLL];
 #pragma unroll
-            for (int u = 0; u < REC_UNROLL; ++u) e[u] = r[i0 + u * QBLOCK < cnt ? i0 + u * QBLOCK : i0];
+            for (int u = 0; u < REC_UNROLL; ++u) e[u] = r[i0 + u * RBLOCK < cnt ? i0 + u * RBLOCK : i0];
 #pragma unroll
             for (int u = 0; u < REC_UNROLL; ++u) {
                 unsigned t, mult;
                 bool none;
                 const int cq = record_list<NQ>(s_br, e[u], t, mult, none);
-                if (none || i0 + u * QBLOCK >= cnt) continue;
+                if (none || i0 + u * RBLOCK >= cnt) continue;
                 const int bin = (int)__umulhi(t, mult);
                 const int2 want = s_bin[cq];
                 const int hit = want.x == bin ? 0 : (want.y == bin ? 1 : -1);
@@ -1095,7 +1185,7 @@ __global__ __launch_bounds__(QBLOCK) void record_compact_kernel(const pem::Recor
     }
     __syncthreads();
     // what this workgroup appended, onto the lists' counters: select_kernel compares them with the counts (the "incomplete" check)
-    for (int i = threadIdx.x; i < 2 * lists; i += QBLOCK) {
+    for (int i = threadIdx.x; i < 2 * lists; i += RBLOCK) {
         const unsigned wrote = s_cur[i] - my_off[i];
         if (wrote) atomicAdd(&tg[i].cursor, (u64)wrote);
     }
@@ -1214,9 +1304,25 @@ extern "C" int pem_quantiles_last_path(void) { return g_last_path.load(); }
 // and pass A / pass B are the producer's counting launch and two passes over its records (csrc/pem_qfused.h).  *fused_ok = 0: the
 // brackets were unfit for the producer, a rank fell outside its bracket, or the producer reported an overflow or a non-finite
 // sample -- `out` is then not written and the caller takes the passes over the array itself.
+// The buffers a selection keeps between calls (grow-only).  Two sets: calls are serialised on a set, and the second one lets the
+// scalar QoIs of a campaign be selected on another host thread and stream while the fused form is busy with the profile's records.
+namespace {
+struct QWork {
+    std::mutex mu;
+    char* ws_buf = nullptr;
+    size_t ws_cap = 0, cand_cap = 0, rec_cap = 0;
+    u64* cand_buf = nullptr;
+    pem::Record* rec_buf = nullptr;
+    unsigned* part_buf = nullptr;              // fused form: the record histograms of every workgroup | their offsets into the lists
+    size_t part_cap = 0;
+    int ws_dev = -1;
+};
+QWork g_qwork[2];
+}  // namespace
+
 static int quantiles_impl(size_t n, int m, const double* data, size_t ld, size_t cs, int nq, const uint64_t* rank_prev,
                           const uint64_t* rank_next, const double* gamma, double* out, pem_stream_t stream, pem::FusedProducer* fused,
-                          int* fused_ok) {
+                          int* fused_ok, int slot = 0) {
     if (m < 1 || m > 64 * MAX_NC) return pem::fail(PEM_ERR_INVALID_ARG, "pem_quantiles: 1 <= m <= %d columns", 64 * MAX_NC);
     if (fused && (m > 128 || !fused_ok)) return pem::fail(PEM_ERR_INVALID_ARG, "pem_quantiles: the fused form takes up to 128 columns");
     if (cs < 1 || (cs == 1 ? ld < (size_t)m : (ld != 1 || cs < n)))
@@ -1263,15 +1369,14 @@ static int quantiles_impl(size_t n, int m, const double* data, size_t ld, size_t
     const size_t b_rc = sizeof(unsigned) * fused_waves;
     const size_t o_br = o_tot + 256, o_bl = o_br + up(b_br), o_hA = o_bl + up(b_bl), o_rc = o_hA + up(b_hA), o_pm = o_rc + up(b_rc);
     const size_t o_end = o_pm + up(sizeof(uint4) * (size_t)m);
-    static std::mutex mu;
-    static char* ws_buf = nullptr;
-    static size_t ws_cap = 0, cand_cap = 0, rec_cap = 0;
-    static u64* cand_buf = nullptr;
-    static pem::Record* rec_buf = nullptr;
-    static unsigned* part_buf = nullptr;              // fused form: the record histograms of every workgroup | their offsets into the lists
-    static size_t part_cap = 0;
-    static int ws_dev = -1;
-    std::lock_guard<std::mutex> lock(mu);
+    QWork& work = g_qwork[slot];
+    std::lock_guard<std::mutex> lock(work.mu);
+    char*& ws_buf = work.ws_buf;
+    size_t &ws_cap = work.ws_cap, &cand_cap = work.cand_cap, &rec_cap = work.rec_cap, &part_cap = work.part_cap;
+    u64*& cand_buf = work.cand_buf;
+    pem::Record*& rec_buf = work.rec_buf;
+    unsigned*& part_buf = work.part_buf;
+    int& ws_dev = work.ws_dev;
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev != ws_dev || ws_cap < o_end) {
@@ -1396,7 +1501,8 @@ static int quantiles_impl(size_t n, int m, const double* data, size_t ld, size_t
 #define Q_BY_NQ_4 Q_BY_NQ_SMALL
 
     // the four passes over rows 0, step, 2 step, ... (`rows` of them, leading dimension ldd): x_(rank) of every target ends in tg[].answer
-    auto four_passes = [&](size_t rows, size_t ldd, const Wanted& ww) -> int {
+    // (edges: stop after the second histogram and take the sub-bins' first / last keys as the answers -- pilot_edges_kernel)
+    auto four_passes = [&](size_t rows, size_t ldd, const Wanted& ww, bool edges = false) -> int {
         const dim3 grid = grid_for(rows);
         Q_TRY(hipMemsetAsync(hist1, 0, o_tot + 256 - o_h1, st));            // hist1, hist2, total
         hipLaunchKernelGGL(init_columns_kernel, dim3(cblocks), dim3(64), 0, st, col, tg, m, nq, ww);
@@ -1414,6 +1520,11 @@ static int quantiles_impl(size_t n, int m, const double* data, size_t ld, size_t
 #define Q_HIST2(NC_) Q_BY_NT_##NC_(Q_HIST2_, NC_)
         Q_BY_NC(Q_HIST2);
         hipLaunchKernelGGL(decide2_kernel, dim3((unsigned)(m * nt)), dim3(64), 0, st, nt, hist2, bins2, tg);
+        if (edges) {
+            hipLaunchKernelGGL(pilot_edges_kernel, dim3((unsigned)((m * nt + 63) / 64)), dim3(64), 0, st, m * nt, nt, bins2, col, tg);
+            Q_TRY(hipGetLastError());
+            return PEM_OK;
+        }
         hipLaunchKernelGGL(layout_kernel, dim3(1), dim3(64 * MAX_NC), 0, st, m, nt, tg, total);
         Q_TRY(hipGetLastError());
         u64 h_total = 0;
@@ -1440,7 +1551,10 @@ static int quantiles_impl(size_t n, int m, const double* data, size_t ld, size_t
         const double n1 = n > 1 ? (double)(n - 1) : 1.0, np1 = (double)(rows_p - 1);
         for (int q = 0; q < nq; ++q) {
             const double p_lo = (double)rank_prev[q] / n1, p_hi = (double)rank_next[q] / n1;
-            const double d_lo = 7.0 * sqrt((double)rows_p * p_lo * (1.0 - p_lo)) + 8.0, d_hi = 7.0 * sqrt((double)rows_p * p_hi * (1.0 - p_hi)) + 8.0;
+            // (the fused form: 6 -- every value inside a bracket costs a record, and a rank outside its bracket, once in a million
+            // campaigns of 91 x 5 brackets, is noticed by the counts and costs a second run)
+            const double sig = fused ? 6.0 : 7.0;
+            const double d_lo = sig * sqrt((double)rows_p * p_lo * (1.0 - p_lo)) + 8.0, d_hi = sig * sqrt((double)rows_p * p_hi * (1.0 - p_hi)) + 8.0;
             const double r_lo = floor(p_lo * np1 - d_lo) - 1.0, r_hi = ceil(p_hi * np1 + d_hi) + 1.0;
             ends.open_lo[q] = r_lo < 0.0;
             ends.open_hi[q] = r_hi > np1;
@@ -1449,7 +1563,8 @@ static int quantiles_impl(size_t n, int m, const double* data, size_t ld, size_t
         }
         if (fused) {                                                        // the producer writes the pilot rows (contiguous) first
             if (int rc = fused->pilot(rows_p, const_cast<double*>(data), st)) return cleanup(rc);
-            if (int rc = four_passes(rows_p, ld, pw)) return rc;
+            const bool edges = !(getenv("PEM_FUSED_PILOT_EXACT") && atoi(getenv("PEM_FUSED_PILOT_EXACT")));
+            if (int rc = four_passes(rows_p, ld, pw, edges)) return rc;
         } else if (int rc = four_passes(rows_p, ld * (size_t)pilot, pw)) return rc;
         // 2. pass A over everything: below / inside counts; the ranks inside their brackets become sub-bins
         const dim3 grid = grid_for(n);
@@ -1528,7 +1643,7 @@ static int quantiles_impl(size_t n, int m, const double* data, size_t ld, size_t
     do {                                                                                                                     \
         static pem::LdsAttrOnce attr;                                                                                        \
         Q_TRY(attr.ensure(reinterpret_cast<const void*>(record_hist_kernel<NQ_>), 148 * 1024)); /* (+ 12 KB of static tables) */ \
-        hipLaunchKernelGGL(record_hist_kernel<NQ_>, dim3((unsigned)cus), blk, (size_t)m * nq * binsA * 4, st, rec_buf, rec_count, rcap, fused_waves, \
+        hipLaunchKernelGGL(record_hist_kernel<NQ_>, dim3((unsigned)cus), dim3(RBLOCK), (size_t)m * nq * binsA * 4, st, rec_buf, rec_count, rcap, fused_waves, \
                            br, m * nq, binsA, part_buf);                                                                     \
     } while (0)
             switch (nq) {
@@ -1540,8 +1655,10 @@ static int quantiles_impl(size_t n, int m, const double* data, size_t ld, size_t
                 default: Q_RECHIST(6); break;
             }
 #undef Q_RECHIST
-            hipLaunchKernelGGL(record_reduce_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, part_buf, cus, cells, histA);
-            hipLaunchKernelGGL(record_total_check_kernel, dim3(1), blk, 0, st, rec_count, rcap, fused_waves, histA, m * nq * binsA, inconsistent, prod_flags);
+            u64* rec_sums = total + 16;                                         // (zeroed with `total` above)
+            hipLaunchKernelGGL(record_reduce_kernel, dim3((unsigned)((cells + 63) / 64)), dim3(256), 0, st, part_buf, cus, cells, histA, rec_count, rcap,
+                               fused_waves, rec_sums);
+            hipLaunchKernelGGL(record_total_check_kernel, dim3(1), dim3(64), 0, st, rec_sums, inconsistent, prod_flags);
         }
         hipLaunchKernelGGL(decide_bracket_kernel, dim3((unsigned)(m * nt)), dim3(64), 0, st, nt, col, br, below, histA, binsA, tg, outside);
         hipLaunchKernelGGL(layout_kernel, dim3(1), dim3(64 * MAX_NC), 0, st, m, nt, tg, total);
@@ -1570,7 +1687,7 @@ static int quantiles_impl(size_t n, int m, const double* data, size_t ld, size_t
                 unsigned* woff = part_buf + (size_t)cus * m * nq * binsA;
                 hipLaunchKernelGGL(record_offsets_kernel, dim3((unsigned)(m * nt)), dim3(64), 0, st, nt, binsA, tg, part_buf, cus, m * nq * binsA, woff);
 #define Q_RECCOMPACT(NQ_) \
-    hipLaunchKernelGGL(record_compact_kernel<NQ_>, dim3((unsigned)cus), blk, 0, st, rec_buf, rec_count, rcap, fused_waves, br, m * nq, tg, woff, cand)
+    hipLaunchKernelGGL(record_compact_kernel<NQ_>, dim3((unsigned)cus), dim3(RBLOCK), 0, st, rec_buf, rec_count, rcap, fused_waves, br, m * nq, tg, woff, cand)
                 switch (nq) {
                     case 1: Q_RECCOMPACT(1); break;
                     case 2: Q_RECCOMPACT(2); break;
@@ -1610,7 +1727,7 @@ static int quantiles_impl(size_t n, int m, const double* data, size_t ld, size_t
                          "pem_quantiles: the list of column %llu, rank %llu holds %llu values where %llu were counted (internal error; result "
                          "discarded; path %d)",
                          h_incomplete[1] / nt, h_incomplete[1] % nt, h_incomplete[2], h_incomplete[3], path);
-    g_last_path.store(path);
+    if (slot == 0) g_last_path.store(path);
     if (fused_ok) *fused_ok = 1;
 #undef Q_BRCOMPACT
 #undef Q_BRCOMPACT_
@@ -1646,6 +1763,11 @@ extern "C" int pem_quantiles_strided_f64_dev(size_t n, int m, const double* data
 int pem::quantiles_fused(size_t n, int m, int nq, const uint64_t* rank_prev, const uint64_t* rank_next, const double* gamma, double* pilot_rows,
                          pem::FusedProducer& prod, double* out, int* fused_ok, hipStream_t st) {
     return quantiles_impl(n, m, pilot_rows, (size_t)m, 1, nq, rank_prev, rank_next, gamma, out, static_cast<pem_stream_t>(st), &prod, fused_ok);
+}
+
+int pem::quantiles_side(size_t n, int m, const double* data, size_t ld, size_t cs, int nq, const uint64_t* rank_prev, const uint64_t* rank_next,
+                        const double* gamma, double* out, hipStream_t st) {
+    return quantiles_impl(n, m, data, ld, cs, nq, rank_prev, rank_next, gamma, out, static_cast<pem_stream_t>(st), nullptr, nullptr, 1);
 }
 
 extern "C" int pem_quantiles_f64_dev(size_t n, int m, const double* data, size_t ld, int nq, const uint64_t* rank_prev, const uint64_t* rank_next,
@@ -1768,30 +1890,6 @@ __device__ __forceinline__ Scale column_scale(u64 kmin, u64 kmax, int bins1) {  
     return sc;
 }
 
-// The keys of bin b (bins2 = 1, g = b) or of sub-bin (b, sb) (g = b bins2 + sb) of a column's binning, [klo, khi], by bisection on
-// the monotone map d -> bin(d) bins2 + sub-bin(d).  The streaming passes test a value's HIGH word against these ranges (two 32-bit
-// instructions per wanted bin) before they bin it in full: a value outside every wanted bin -- all but a few per cent -- costs
-// neither the 64-bit subtraction nor the quarter-rate multiply of bin_of.  An empty bin comes out as klo > khi.
-__device__ __forceinline__ void keys_of_bin(const Scale& sc, u64 kmax, int bins2, long long g, u64& klo, u64& khi) {
-    const u64 D = kmax >= sc.lo ? (kmax - sc.lo) >> sc.shift : 0;
-    auto first = [&](long long G) {
-        u64 lo = 0, hi = D + 1;
-        while (lo < hi) {
-            const u64 mid = (lo + hi) >> 1, prod = mid * sc.mult;
-            const long long gd = (long long)(prod >> 32) * bins2 + (bins2 > 1 ? (long long)__umulhi((unsigned)prod, (unsigned)bins2) : 0);
-            if (gd >= G) hi = mid;
-            else lo = mid + 1;
-        }
-        return lo;
-    };
-    const u64 d0 = first(g), d1 = first(g + 1);
-    klo = sc.lo + (d0 << sc.shift);
-    khi = d1 > D ? kmax : sc.lo + (d1 << sc.shift) - 1;
-    if (d0 > D || d0 >= d1) {
-        klo = ~0ull;
-        khi = 0ull;
-    }
-}
 
 __global__ void qsel_init_kernel(int m, u64* kmin, u64* kmax, int* has_nan) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;

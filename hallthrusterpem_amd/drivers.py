@@ -343,16 +343,25 @@ def forward_uq_statistics(n: int, seed: int = 0, keep_profile: bool = True, perc
     pct = [25.0, 75.0] + [float(x) for x in percentiles]
     if len(pct) > MAX_Q:
         raise ValueError(f'at most {MAX_Q - 2} percentiles besides the quartiles')
-    answered, premasked, qj, certain, uncertain = False, False, None, None, None
+    answered, premasked, qj, qs, certain, uncertain = False, False, None, None, None, None
     thresh = int(0.75 * _lib.NANGLE)
-    with torch.cuda.device(batch.device):
-        stream = torch.cuda.current_stream(batch.device)
+    nv, cap = len(QOI_NAMES), 65536
+    dev = batch.device
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev)
+        # (what the masks pass below writes is allocated before the evaluation is enqueued: nothing between the two calls but the call)
+        nan_s = torch.empty((nv + 1, n), dtype=torch.bool, device=dev)      # rows: the scalar outputs, then the profile
+        out_s = torch.empty((nv + 1, n), dtype=torch.bool, device=dev)
+        open_rows = torch.empty(cap, dtype=torch.int64, device=dev)
+        open_count = torch.zeros(1, dtype=torch.int32, device=dev)
         if fused and n >= FUSED_STATS_MIN_N:
             rp, rn, gm = _linear_ranks(n, pct)
-            qj = torch.empty((len(pct), _lib.NANGLE), dtype=torch.float64, device=batch.device)
-            pilot = None if keep_profile else torch.empty(((n + 31) // 32, _lib.NANGLE), dtype=torch.float64, device=batch.device)
-            certain = torch.empty(n, dtype=torch.uint8, device=batch.device)
-            uncertain = torch.empty(n, dtype=torch.uint8, device=batch.device)
+            qj = torch.empty((len(pct), _lib.NANGLE), dtype=torch.float64, device=dev)
+            # (the scalar QoIs' percentiles are selected by the same call, on a second stream, while the profile's records are sorted)
+            qs = torch.empty((len(pct), nv), dtype=torch.float64, device=dev)
+            pilot = None if keep_profile else torch.empty(((n + 31) // 32, _lib.NANGLE), dtype=torch.float64, device=dev)
+            certain = torch.empty(n, dtype=torch.uint8, device=dev)
+            uncertain = torch.empty(n, dtype=torch.uint8, device=dev)
             ok, pm_ok = C.c_int(0), C.c_int(0)
             ptr = lambda arr: C.c_void_p(arr.ctypes.data)                                       # noqa: E731
             outs = batch._out_ptrs
@@ -360,7 +369,7 @@ def forward_uq_statistics(n: int, seed: int = 0, keep_profile: bool = True, perc
                 n, 0, design.seed, design.stream, ptr(design.kind), ptr(design.a), ptr(design.b), constants.TORR_2_PA, batch.radius,
                 C.c_void_p(batch.inputs.data_ptr()) if keep_inputs else None, batch.inputs.stride(0),
                 outs[0], outs[1], outs[2], outs[3], None if pilot is None else C.c_void_p(pilot.data_ptr()), outs[4], outs[5], outs[6],
-                len(pct), ptr(rp), ptr(rn), ptr(gm), C.c_void_p(qj.data_ptr()), C.byref(ok),
+                len(pct), ptr(rp), ptr(rn), ptr(gm), C.c_void_p(qj.data_ptr()), C.c_void_p(qs.data_ptr()), C.byref(ok),
                 0, 1, float(iqr_factor), C.c_void_p(certain.data_ptr()), C.c_void_p(uncertain.data_ptr()), C.byref(pm_ok),
                 C.c_void_p(stream.cuda_stream)))
             answered, premasked = bool(ok.value), bool(pm_ok.value)
@@ -368,7 +377,7 @@ def forward_uq_statistics(n: int, seed: int = 0, keep_profile: bool = True, perc
         else:
             batch.run_mc(design, first_index=0, write_inputs=keep_inputs)
     out = {k: batch.qoi[i] for i, k in enumerate(QOI_NAMES)}
-    out.update(I_B0=batch.I_B0, T=batch.T, invalid=batch.invalid.bool())
+    out.update(I_B0=batch.I_B0, T=batch.T, invalid=batch.invalid.view(torch.bool))            # (bytes 0 / 1: the same storage)
     if keep_inputs:
         out['x'] = batch.inputs
     if keep_profile:
@@ -381,29 +390,44 @@ def forward_uq_statistics(n: int, seed: int = 0, keep_profile: bool = True, perc
             full = CoupledBatch(n, device=device, profile=True, thruster_qoi=False)
             full.run_mc(design, first_index=0)
             qj = column_percentiles(full.j_ion, pct)
-    qs = column_percentiles(batch.qoi.T, pct)                      # the three scalar QoIs in one selection
+    if qs is None:
+        qs = column_percentiles(batch.qoi.T, pct)                  # the three scalar QoIs in one selection
     q = {k: qs[:, i] for i, k in enumerate(QOI_NAMES)}
     q['j_ion'] = qj
     nan_idx, outlier_idx, bands = {}, {}, {}
-    for k in QOI_NAMES:
-        iqr = q[k][1] - q[k][0]
-        nan_idx[k], count = _row_masks(out[k], q[k][0] - iqr_factor * iqr, q[k][1] + iqr_factor * iqr, 1)
-        outlier_idx[k] = count > 0
+    # the scalar outputs' masks (a variable of one entry per sample is an outlier when that entry lies outside p25 - f iqr .. p75 + f iqr)
+    # and the verdict of the profile's premask counts: one pass, one thread per sample (`pem_campaign_masks_f64_dev`)
+    dp = lambda t: C.c_void_p(t.data_ptr())                                                       # noqa: E731
+    with torch.cuda.device(dev):
+        vars_ = (C.c_void_p * nv)(*[batch.qoi[i].data_ptr() for i in range(nv)])
+        _lib.check(_lib.load().pem_campaign_masks_f64_dev(
+            n, nv, vars_, dp(qs), qs.stride(0), 0, 1, float(iqr_factor), dp(nan_s), dp(out_s), dp(certain) if premasked else None,
+            dp(uncertain) if premasked else None, thresh, dp(open_rows), dp(open_count), cap, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    for i, k in enumerate(QOI_NAMES):
+        nan_idx[k], outlier_idx[k] = nan_s[i], out_s[i]
     # the profile's masks (gen_data.py:160-168): NaN per sample, more than int(0.75 * 91) values outside [p25 - f iqr, p75 + f iqr]
-    iqr = qj[1] - qj[0]
-    lo, hi = qj[0] - iqr_factor * iqr, qj[1] + iqr_factor * iqr
+
+    def profile_bounds():
+        iqr = qj[1] - qj[0]
+        return qj[0] - iqr_factor * iqr, qj[1] + iqr_factor * iqr
     if premasked:
         # counted by the evaluation launch against INTERVALS for the bounds: a sample is settled unless its uncertain values could
         # change the verdict -- those few (none, as a rule) are looked at again with the exact bounds
-        c, u = certain.to(torch.int32), uncertain.to(torch.int32)
-        outl = c > thresh
-        open_rows = torch.nonzero((~outl) & (c + u > thresh)).flatten()
-        if open_rows.numel():
-            rows = batch.j_ion[open_rows] if keep_profile else _profile_rows(design, open_rows, device=batch.device)
-            outl[open_rows] = ((rows < lo) | (rows > hi)).sum(dim=1) > thresh
-        nan_idx['j_ion'] = torch.zeros(n, dtype=torch.bool, device=batch.device)     # (a non-finite value makes the selection decline)
+        n_open = int(open_count.item())
+        if n_open > cap:                                                  # (a list that did not fit: the same test in torch)
+            c, u = certain.to(torch.int32), uncertain.to(torch.int32)
+            rows_open = torch.nonzero((c <= thresh) & (c + u > thresh)).flatten()
+        else:
+            rows_open = open_rows[:n_open]
+        outl = out_s[nv]
+        if rows_open.numel():
+            lo, hi = profile_bounds()
+            rows = batch.j_ion[rows_open] if keep_profile else _profile_rows(design, rows_open, device=dev)
+            outl[rows_open] = ((rows < lo) | (rows > hi)).sum(dim=1) > thresh
+        nan_idx['j_ion'] = nan_s[nv]                                                 # (zeros: a non-finite value makes the selection decline)
         outlier_idx['j_ion'] = outl
     else:
+        lo, hi = profile_bounds()
         prof = batch.j_ion if keep_profile else (full.j_ion if full is not None else None)
         if prof is None:                     # answered on chip but no premask (bounds it cannot take): the profile once, for the masks
             full = CoupledBatch(n, device=device, profile=True, thruster_qoi=False)

@@ -335,14 +335,18 @@ int pem_quantiles_last_path(void);
  * (the quartiles lie in their brackets), and the counting launch also writes, per sample, how many of its 91 values lie outside
  * the bounds FOR CERTAIN and how many are UNCERTAIN (inside one of the two intervals).  certain > int(0.75 * 91) is an outlier,
  * certain + uncertain <= that is not, and the caller settles the rest from the exact bounds: gen_data.py:166-168 without a pass
- * over the profile.  *premask_ok = 0: not produced (bounds zero or not finite, f < 0, nq > 5, or the selection declined).            */
+ * over the profile.  *premask_ok = 0: not produced (bounds zero or not finite, f < 0, nq > 5, or the selection declined).
+ * q_scalars (optional; [nq][3] on the device): the same nq percentiles of V_cc, div_angle and T_c -- which must then be rows 0, 1, 2
+ * of one array (the [3][n] reduced-QoI tensor of a batch) -- as pem_quantiles_strided_f64_dev gives them, selected on a second
+ * thread and a stream of the library's own while the calling thread takes the profile's records through their passes; written
+ * whether or not the profile's selection declined.                                                                                */
 #define PEM_MC_STATS_MIN_N 4096
 int pem_coupled_mc_stats_f64_dev(size_t n, uint64_t first_index, uint64_t seed, uint32_t stream_id, const int32_t* kind, const double* a,
                                  const double* b, double torr2pa, double radius, double* x_out, size_t ld, double* V_cc, double* I_B0,
                                  double* T, double* j_ion, double* pilot_rows, double* div_angle, double* T_c, uint8_t* invalid, int nq,
-                                 const uint64_t* rank_prev, const uint64_t* rank_next, const double* gamma, double* q_out, int* fused_ok,
-                                 int q25, int q75, double iqr_factor, uint8_t* row_certain, uint8_t* row_uncertain, int* premask_ok,
-                                 pem_stream_t stream);
+                                 const uint64_t* rank_prev, const uint64_t* rank_next, const double* gamma, double* q_out, double* q_scalars,
+                                 int* fused_ok, int q25, int q75, double iqr_factor, uint8_t* row_certain, uint8_t* row_uncertain,
+                                 int* premask_ok, pem_stream_t stream);
 
 /* The per-sample masks of `_filter_outputs` (scripts/gen_data.py:150-168) for one output variable in one pass over it
  * (csrc/pem_masks.hip): data [n][ld] row-major, entries 0..m-1 of a sample; lo / hi: m per-entry bounds each (DEVICE arrays:
@@ -353,6 +357,20 @@ int pem_coupled_mc_stats_f64_dev(size_t n, uint64_t first_index, uint64_t seed, 
 #define PEM_ROW_MASKS_MAX_M 512
 int pem_row_masks_f64_dev(size_t n, int m, const double* data, size_t ld, const double* lo, const double* hi, uint8_t* nan_out,
                           int32_t* outside_out, pem_stream_t stream);
+
+/* The masks of a campaign's SCALAR outputs and the verdict of the profile's premask counts in one pass, one thread per sample
+ * (drivers.forward_uq_statistics; gen_data.py:150-168 for variables of one entry per sample): vars: HOST array of nvar <= 8 device
+ * pointers to n values each; q: the variables' percentiles on the device, rows of nvar values q_ld apart (pem_coupled_mc_stats_f64_dev's
+ * q_scalars), of which rows row25 / row75 are the quartiles: the bounds are p25 - f iqr and p75 + f iqr, rounded as numpy rounds them;
+ * nan_out / outl_out [nvar][n] bytes (0 / 1: np.isnan(x); (x < lo) | (x > hi)).  With row_certain / row_uncertain (the per-sample counts
+ * of pem_coupled_mc_stats_f64_dev's premask; both or neither) the arrays have one row more, the profile's: nan_out[nvar][i] = 0,
+ * outl_out[nvar][i] = certain > thresh, and the samples with certain <= thresh < certain + uncertain -- whose verdict the exact bounds
+ * must settle -- are appended to open_rows (int64, room for `cap`; unordered) and counted in *open_count (device int32, zeroed by the
+ * caller; more than cap: the list is incomplete).  Asynchronous on `stream`.                                                       */
+int pem_campaign_masks_f64_dev(size_t n, int nvar, const double* const* vars, const double* q, int q_ld, int row25, int row75,
+                               double iqr_factor, uint8_t* nan_out,
+                               uint8_t* outl_out, const uint8_t* row_certain, const uint8_t* row_uncertain, int thresh,
+                               int64_t* open_rows, int32_t* open_count, int cap, pem_stream_t stream);
 
 /* The multi-rank building blocks of the same selection (samples sharded over GPUs; hallthrusterpem_amd/percentiles.py drives the
  * levels and all-reduces between them): per-column min / max of the order-preserving 64-bit image of the values (sign bit

@@ -545,3 +545,58 @@ def test_two_ranks_sharing_the_gpu_get_the_percentiles_of_the_whole_campaign(tmp
         port = s.getsockname()[1]
     mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / 'ok0').exists() and (tmp_path / 'ok1').exists()
+
+
+@pytest.mark.gpu
+def test_campaign_masks_entry_point_equals_numpy():
+    """pem_campaign_masks_f64_dev: the masks of scalar outputs (NaN; outside p25 - f iqr .. p75 + f iqr with numpy's roundings) and the
+    verdict of the premask counts (outlier for certain, settled, or listed as open), against numpy on crafted arrays."""
+    import ctypes as C
+    import torch
+    from hallthrusterpem_amd import _lib
+    rng = np.random.default_rng(11)
+    n, nv, f, thresh = 100_003, 3, 1.5, 68
+    x = rng.standard_normal((nv, n)) * np.array([[1.0], [1e-3], [250.0]]) + np.array([[30.0], [0.2], [-4.0]])
+    x[1, ::977] = np.nan
+    x[2, 5] = np.inf
+    q = np.stack([np.nanpercentile(x, p, axis=1) for p in (25.0, 75.0, 5.0, 50.0, 95.0)])          # [5][3]
+    certain = rng.integers(0, 92, n).astype(np.uint8)
+    uncertain = np.minimum(91 - certain, rng.integers(0, 4, n)).astype(np.uint8)
+    xd, qd = torch.from_numpy(x).cuda(), torch.from_numpy(q).cuda()
+    cd, ud = torch.from_numpy(certain).cuda(), torch.from_numpy(uncertain).cuda()
+    nan_o = torch.full((nv + 1, n), 7, dtype=torch.uint8, device='cuda')
+    out_o = torch.full((nv + 1, n), 7, dtype=torch.uint8, device='cuda')
+    cap = 64
+    rows = torch.full((cap,), -1, dtype=torch.int64, device='cuda')
+    count = torch.zeros(1, dtype=torch.int32, device='cuda')
+    p = lambda t: C.c_void_p(t.data_ptr())                                                   # noqa: E731
+    vars_ = (C.c_void_p * nv)(*[xd[i].data_ptr() for i in range(nv)])
+    lib = _lib.load()
+    _lib.check(lib.pem_campaign_masks_f64_dev(n, nv, vars_, p(qd), qd.stride(0), 0, 1, f, p(nan_o), p(out_o), p(cd), p(ud), thresh, p(rows), p(count),
+                                              cap, None))
+    torch.cuda.synchronize()
+    iqr = q[1] - q[0]
+    lo, hi = q[0] - f * iqr, q[1] + f * iqr
+    with np.errstate(invalid='ignore'):
+        want_out = (x < lo[:, None]) | (x > hi[:, None])
+    assert np.array_equal(nan_o[:nv].cpu().numpy().astype(bool), np.isnan(x))
+    assert np.array_equal(out_o[:nv].cpu().numpy().astype(bool), want_out)
+    assert not nan_o[nv].any() and np.array_equal(out_o[nv].cpu().numpy().astype(bool), certain > thresh)
+    open_want = np.nonzero((certain <= thresh) & (certain.astype(int) + uncertain > thresh))[0]
+    n_open = int(count.item())
+    assert n_open == open_want.size > cap                    # more than the list holds: counted all the same, the first `cap` listed
+    listed = rows.cpu().numpy()
+    assert np.all(np.isin(listed, open_want)) and np.unique(listed).size == cap
+    # a list that fits; without the premask counts the profile's row is left alone
+    rows2 = torch.full((open_want.size + 8,), -1, dtype=torch.int64, device='cuda')
+    count.zero_()
+    _lib.check(lib.pem_campaign_masks_f64_dev(n, nv, vars_, p(qd), qd.stride(0), 0, 1, f, p(nan_o), p(out_o), p(cd), p(ud), thresh, p(rows2), p(count),
+                                              rows2.numel(), None))
+    assert np.array_equal(np.sort(rows2[:int(count.item())].cpu().numpy()), open_want)
+    nan_o.fill_(7)
+    _lib.check(lib.pem_campaign_masks_f64_dev(n, nv, vars_, p(qd), qd.stride(0), 0, 1, f, p(nan_o), p(out_o), None, None, thresh, None, None, 0, None))
+    torch.cuda.synchronize()
+    assert bool((nan_o[nv] == 7).all()) and np.array_equal(nan_o[:nv].cpu().numpy().astype(bool), np.isnan(x))
+    assert lib.pem_campaign_masks_f64_dev(n, 9, vars_, p(qd), qd.stride(0), 0, 1, f, p(nan_o), p(out_o), None, None, thresh, None, None, 0, None) == 1
+    assert lib.pem_campaign_masks_f64_dev(n, nv, vars_, p(qd), 2, 0, 1, f, p(nan_o), p(out_o), None, None, thresh, None, None, 0, None) == 1
+    assert lib.pem_campaign_masks_f64_dev(n, nv, vars_, p(qd), qd.stride(0), 0, 1, f, p(nan_o), p(out_o), p(cd), None, thresh, None, None, 0, None) == 1
