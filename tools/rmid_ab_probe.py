@@ -1,7 +1,12 @@
+#!/usr/bin/env python3
+"""current_density with 17 ... 64 sweep radii (the staged kernel, csrc/pem_kernels.hip plume_rmid_kernel): TB/s of output per radius count.
+Set PEM_HIP_LIB=build_variants/libpem_<name>.so (tools/build_variant_fast.sh) to compare variants, one process per variant, interleaved
+by the caller; `profiles/radii_mid_r04.txt`."""
 import os, sys
 from pathlib import Path
 import numpy as np, torch
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / 'tests'))
 from _inputs import plume_inputs
 from hallthrusterpem_amd.models import current_density
 for R in (17, 25, 32, 33, 48, 64):

@@ -1,6 +1,11 @@
+#!/usr/bin/env python3
+"""One fuzz seed of tools/fuzz_parity.py looked at closely: the worst div_angle sample, its inputs, cos(got) - cos(want) and the bound's
+terms (how seed 5160 -- an arccos pole, DESIGN section 2 -- was diagnosed).  python tools/seed_probe.py [seed]"""
+from pathlib import Path
 import sys
 import numpy as np
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests'); sys.path.insert(0, '/root/repo/tools')
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / 'tests')); sys.path.insert(0, str(ROOT / 'tools'))
 import fuzz_parity as fp
 import parity_rules as pr
 from oracle import oracle_ctypes as oc

@@ -73,7 +73,7 @@ lines.append('')
 sys.path.insert(0, str(ROOT))
 from bench import kernel_source_hash     # noqa: E402  (the digest bench.py checks before it replays this record)
 rec = {'tag': tag, 'samples_per_launch': n_samples, 'kernel': KERNEL, 'kernel_mean_us': kern_mean_us,
-       'kernel_srchash': kernel_source_hash(), 'layout': os.environ.get('PEM_PROFILE_LAYOUT', 'soa')}
+       'kernel_srchash': kernel_source_hash(), 'layout': os.environ.get('PEM_PROFILE_LAYOUT', 'soa' if '--layout soa' in ' '.join(sys.argv) else 'tile')}   # (bench.py's default input layout: tile)
 if 'FETCH_SIZE' in mean and 'WRITE_SIZE' in mean:
     # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reads exactly half the bytes of a wide coalesced
     # stream (128-B requests tallied at 64 B) -> doubled; WRITE_SIZE is exact for 16-B/lane streaming stores.
