@@ -74,7 +74,7 @@ SIGNATURES = {
                                                _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp,
                                                C.c_int, C.c_int, C.c_double, _dp, _dp, _dp, _dp]),
     'pem_row_masks_f64_dev': (C.c_int, [_sz, C.c_int, _dp, _sz, _dp, _dp, _dp, _dp, _dp]),
-    'pem_campaign_masks_f64_dev': (C.c_int, [_sz, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_double, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp,
+    'pem_campaign_masks_f64_dev': (C.c_int, [_sz, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_double, _dp, _dp, _sz, _dp, _dp, C.c_int, _dp, _dp,
                                              C.c_int, _dp]),
     'pem_sobol_partial_f64_dev': (C.c_int, [_sz, C.c_int, _sz, _dp, _dp, _dp, _dp, C.c_int, _dp]),
     'pem_coupled_f32_dev': (C.c_int, [_sz, C.c_float, C.c_float, _dp, _sz, _dp, _sz, _dp, _dp]),

@@ -2485,34 +2485,53 @@ extern "C" {
 
 // ---- coupled, fused Monte-Carlo with the percentiles of the profile counted on the way (round 4) --------------------------------
 namespace {
-// The scalar QoIs' percentiles of a campaign, selected on a second host thread and stream while the calling thread takes the profile's
-// records through their passes (csrc/pem_quantile.hip keeps a second set of buffers for it): the worker waits -- on the host for
-// `go`, on the device for `ev` -- until the launch that writes the scalars is under way.
+// The scalar QoIs' percentiles of a campaign, selected on a second host thread and stream while the calling thread takes the
+// profile through its pilot, its counting launch and the passes over its records (csrc/pem_quantile.hip keeps a second set of
+// buffers for it).  Two stages, each released on the host (a promise) and ordered on the device (an event): the scalars of the
+// pilot's samples exist once the pilot evaluation is under way -- the worker brackets the wanted ranks from them while the
+// counting launch runs -- and all of them once the counting launch (or, after a decline, the plain launch) is.
 struct ScalarJob {
-    std::promise<int> go;                      // 1: `ev` marks the launch that writes the scalars; 0: give up (an error on the calling thread)
-    bool signalled = false;
-    hipEvent_t ev = nullptr;
+    struct Stage {
+        std::promise<int> go;                  // 1: `ev` marks the launch; 0: give up (an error on the calling thread)
+        std::future<int> gone;
+        bool signalled = false;
+        hipEvent_t ev = nullptr;
+        Stage() : gone(go.get_future()) {}
+        void signal(int v) {
+            if (!signalled) {
+                signalled = true;
+                go.set_value(v);
+            }
+        }
+        int launched(hipStream_t st) {         // after the launch has been enqueued on `st`
+            if (signalled) return PEM_OK;
+            HIP_TRY(hipEventRecord(ev, st));
+            signal(1);
+            return PEM_OK;
+        }
+        // the worker: block until the launch is under way, then make `side` wait for it
+        int await(hipStream_t side) {
+            if (gone.get() != 1) return fail(PEM_ERR_HIP, "pem_coupled_mc_stats (scalar selection): given up");
+            HIP_TRY(hipStreamWaitEvent(side, ev, 0));
+            return PEM_OK;
+        }
+    };
+    Stage pilot, full;
     std::thread worker;
     int rc = PEM_OK;
     std::string error;
-    void signal(int v) {
-        if (!signalled) {
-            signalled = true;
-            go.set_value(v);
-        }
-    }
-    // after the launch that (re)writes the scalars has been enqueued on `st`
-    int launched(hipStream_t st) {
-        if (signalled) return PEM_OK;
-        HIP_TRY(hipEventRecord(ev, st));
-        signal(1);
+    int create() {
+        HIP_TRY(hipEventCreateWithFlags(&pilot.ev, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&full.ev, hipEventDisableTiming));
         return PEM_OK;
     }
     int join() {
-        signal(0);
+        pilot.signal(0);
+        full.signal(0);
         if (worker.joinable()) worker.join();
-        if (ev) (void)hipEventDestroy(ev);
-        ev = nullptr;
+        if (pilot.ev) (void)hipEventDestroy(pilot.ev);
+        if (full.ev) (void)hipEventDestroy(full.ev);
+        pilot.ev = full.ev = nullptr;
         return rc;
     }
     ~ScalarJob() { (void)join(); }
@@ -2540,12 +2559,13 @@ struct McProducer : pem::FusedProducer {
         pem::McLaunch p = a;                       // samples 0 .. rows-1 of the same design; their profile rows go to dst
         p.n = rows;
         p.j_ion = dst;
-        return pem::launch_coupled_mc(p, st);
+        if (int rc = pem::launch_coupled_mc(p, st)) return rc;
+        return job ? job->pilot.launched(st) : PEM_OK;   // (their scalars too: the side selection's subsample)
     }
     int waves(int nq, unsigned* w) override { return pem::coupled_count_waves(a.n, nq, store_profile, w); }
     int count(const pem::CountIO& io, hipStream_t st) override {
         if (int rc = pem::launch_coupled_mc_count(a, io, store_profile, st)) return rc;
-        return job ? job->launched(st) : PEM_OK;  // (the scalars' selection may start behind this launch)
+        return job ? job->full.launched(st) : PEM_OK;    // (the side selection's passes over all samples may follow this launch)
     }
 };
 }  // namespace
@@ -2577,19 +2597,22 @@ int pem_coupled_mc_stats_f64_dev(size_t n, uint64_t first_index, uint64_t seed, 
         HIP_TRY(hipGetDevice(&dev));
         hipStream_t side = nullptr;
         if (int rc = side_stream(&side)) return rc;
-        HIP_TRY(hipEventCreateWithFlags(&job.ev, hipEventDisableTiming));
-        std::future<int> go = job.go.get_future();
-        job.worker = std::thread([&job, dev, side, n, nq, V_cc, qstride, rank_prev, rank_next, gamma, q_scalars, go = std::move(go)]() mutable {
-            if (go.get() != 1) return;
-            hipError_t e = hipSetDevice(dev);
-            if (e == hipSuccess) e = hipStreamWaitEvent(side, job.ev, 0);
-            if (e != hipSuccess) {
-                job.rc = PEM_ERR_HIP;
-                job.error = std::string("pem_coupled_mc_stats (scalar selection): ") + hipGetErrorString(e);
+        if (int rc = job.create()) return rc;
+        job.worker = std::thread([&job, dev, side, n, nq, V_cc, qstride, rank_prev, rank_next, gamma, q_scalars]() {
+            auto note = [&job](int rc) {
+                job.rc = rc;
+                if (rc != PEM_OK) job.error = pem_last_error();          // (the message lives in this thread's buffer)
+                return rc;
+            };
+            if (hipSetDevice(dev) != hipSuccess) {
+                (void)note(fail(PEM_ERR_HIP, "pem_coupled_mc_stats (scalar selection): hipSetDevice failed"));
                 return;
             }
-            job.rc = pem::quantiles_side(n, 3, V_cc, 1, (size_t)qstride, nq, rank_prev, rank_next, gamma, q_scalars, side);
-            if (job.rc != PEM_OK) job.error = pem_last_error();      // (the message lives in this thread's buffer)
+            if (note(job.pilot.await(side))) return;
+            pem::SidePlan plan;
+            plan.ctx = &job;
+            plan.before_full = [](void* ctx, hipStream_t st) { return static_cast<ScalarJob*>(ctx)->full.await(st); };
+            (void)note(pem::quantiles_side(n, 3, V_cc, 1, (size_t)qstride, nq, rank_prev, rank_next, gamma, q_scalars, side, &plan));
         });
         prod.job = &job;
     }
@@ -2630,17 +2653,18 @@ int pem_coupled_mc_stats_f64_dev(size_t n, uint64_t first_index, uint64_t seed, 
     if (!*fused_ok) {
         // declined -- possibly before the counting launch, with nothing but the pilot's samples evaluated: the plain launch makes
         // every output complete (a rare path: 1.5 ms per 1e7 samples where the counting launch had already run).  A scalar selection
-        // that started behind the counting launch is let finish first (the plain launch writes the same scalars again).
-        if (q_scalars && job.signalled) {
+        // that went on behind the counting launch is let finish first (the plain launch writes the same scalars again).
+        if (q_scalars && job.full.signalled) {
             if (int rc = job.join()) return fail(rc, "%s", job.error.c_str());
         }
         if (int rc = pem::launch_coupled_mc(prod.a, st)) return rc;
         if (q_scalars) {
-            if (int rc = job.launched(st)) return rc;
+            if (int rc = job.pilot.launched(st)) return rc;               // (no-ops for a stage that has been released)
+            if (int rc = job.full.launched(st)) return rc;
         }
         HIP_TRY(hipStreamSynchronize(st));
     }
-    if (q_scalars) {                               // (signalled by now on every path that comes here)
+    if (q_scalars) {                               // (both stages released by now on every path that comes here)
         if (int rc = job.join()) return fail(rc, "%s", job.error.c_str());
     }
     return PEM_OK;

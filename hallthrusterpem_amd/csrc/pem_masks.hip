@@ -110,9 +110,12 @@ constexpr int CM_MAX_VARS = 8;
 struct CampaignVars {
     const double* v[CM_MAX_VARS];
 };
+// V = 4: four consecutive samples per thread, masks written as 4-byte words (rows of the mask arrays 4-byte aligned: mask_ld a
+// multiple of 4) -- with one byte per store instruction and lane the pass took 104 us per 1e7 samples, bound by its 8e7 byte stores
+template <int V>
 __global__ __launch_bounds__(MBLOCK) void campaign_masks_kernel(long long n, int nvar, CampaignVars vars, const double* __restrict__ q, int q_ld,
                                                                 int row25, int row75, double factor, uint8_t* __restrict__ nan_out,
-                                                                uint8_t* __restrict__ outl_out, const uint8_t* __restrict__ certain,
+                                                                uint8_t* __restrict__ outl_out, size_t mask_ld, const uint8_t* __restrict__ certain,
                                                                 const uint8_t* __restrict__ uncertain, int thresh,
                                                                 long long* __restrict__ open_rows, int* __restrict__ open_count, int cap) {
     // gen_data.py:163-166: iqr = p75 - p25; the bounds p25 - f iqr and p75 + f iqr, every operation rounded on its own as numpy does
@@ -124,24 +127,64 @@ __global__ __launch_bounds__(MBLOCK) void campaign_masks_kernel(long long n, int
         lo[k] = __dsub_rn(p25, __dmul_rn(factor, iqr));
         hi[k] = __dadd_rn(p75, __dmul_rn(factor, iqr));
     }
-    const long long stride = (long long)gridDim.x * MBLOCK;
-    for (long long i = (long long)blockIdx.x * MBLOCK + threadIdx.x; i < n; i += stride) {
+    const long long stride = (long long)gridDim.x * MBLOCK * V;
+    for (long long i = ((long long)blockIdx.x * MBLOCK + threadIdx.x) * V; i < n; i += stride) {
+        const int left = n - i < V ? (int)(n - i) : V;
 #pragma unroll
         for (int k = 0; k < CM_MAX_VARS; ++k) {
             if (k < nvar) {
-                const double x = __builtin_nontemporal_load(vars.v[k] + i);
-                nan_out[(size_t)k * n + i] = (uint8_t)(x != x);                       // np.isnan
-                outl_out[(size_t)k * n + i] = (uint8_t)((x < lo[k]) | (x > hi[k]));   // one entry per sample: "any entry outside" (a NaN compares false)
+                unsigned nanw = 0, outw = 0;
+#pragma unroll
+                for (int u = 0; u < V; ++u) {
+                    const double x = u < left ? __builtin_nontemporal_load(vars.v[k] + i + u) : 0.0;
+                    nanw |= (unsigned)(x != x) << (8 * u);                        // np.isnan
+                    outw |= (unsigned)((x < lo[k]) | (x > hi[k])) << (8 * u);     // one entry per sample: "any entry outside" (a NaN compares false)
+                }
+                uint8_t* np_ = nan_out + (size_t)k * mask_ld + i;
+                uint8_t* op_ = outl_out + (size_t)k * mask_ld + i;
+                if (V == 4 && left == V) {
+                    *reinterpret_cast<unsigned*>(np_) = nanw;
+                    *reinterpret_cast<unsigned*>(op_) = outw;
+                } else {
+                    for (int u = 0; u < left; ++u) {
+                        np_[u] = (uint8_t)(nanw >> (8 * u));
+                        op_[u] = (uint8_t)(outw >> (8 * u));
+                    }
+                }
             }
         }
         if (certain) {
-            const int c = certain[i], u = uncertain[i];
-            const bool out = c > thresh;
-            nan_out[(size_t)nvar * n + i] = 0;                                    // (a non-finite profile value makes the selection decline)
-            outl_out[(size_t)nvar * n + i] = (uint8_t)out;
-            if (!out && c + u > thresh) {                                         // the uncertain values could change the verdict: the caller looks again
-                const int at = atomicAdd(open_count, 1);
-                if (at < cap) open_rows[at] = i;
+            unsigned outw = 0, cw = 0, uw = 0;
+            if (V == 4 && left == V) {                                            // (the counts of four samples as one word each)
+                cw = *reinterpret_cast<const unsigned*>(certain + i);
+                uw = *reinterpret_cast<const unsigned*>(uncertain + i);
+            } else {
+                for (int u = 0; u < left; ++u) {
+                    cw |= (unsigned)certain[i + u] << (8 * u);
+                    uw |= (unsigned)uncertain[i + u] << (8 * u);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < V; ++u) {
+                if (u >= left) break;
+                const int c = (int)((cw >> (8 * u)) & 255u), w = (int)((uw >> (8 * u)) & 255u);
+                const bool out = c > thresh;
+                outw |= (unsigned)out << (8 * u);
+                if (!out && c + w > thresh) {                                     // the uncertain values could change the verdict: the caller looks again
+                    const int at = atomicAdd(open_count, 1);
+                    if (at < cap) open_rows[at] = i + u;
+                }
+            }
+            uint8_t* np_ = nan_out + (size_t)nvar * mask_ld + i;                  // (zeros: a non-finite profile value makes the selection decline)
+            uint8_t* op_ = outl_out + (size_t)nvar * mask_ld + i;
+            if (V == 4 && left == V) {
+                *reinterpret_cast<unsigned*>(np_) = 0u;
+                *reinterpret_cast<unsigned*>(op_) = outw;
+            } else {
+                for (int u = 0; u < left; ++u) {
+                    np_[u] = 0;
+                    op_[u] = (uint8_t)(outw >> (8 * u));
+                }
             }
         }
     }
@@ -151,13 +194,14 @@ __global__ __launch_bounds__(MBLOCK) void campaign_masks_kernel(long long n, int
 
 extern "C" int pem_campaign_masks_f64_dev(size_t n, int nvar, const double* const* vars, const double* q, int q_ld, int row25, int row75,
                                           double iqr_factor, uint8_t* nan_out,
-                                          uint8_t* outl_out, const uint8_t* row_certain, const uint8_t* row_uncertain, int thresh,
+                                          uint8_t* outl_out, size_t mask_ld, const uint8_t* row_certain, const uint8_t* row_uncertain, int thresh,
                                           int64_t* open_rows, int32_t* open_count, int cap, pem_stream_t stream) {
     if (nvar < 0 || nvar > CM_MAX_VARS) return pem::fail(PEM_ERR_INVALID_ARG, "pem_campaign_masks: 0 <= nvar <= %d", CM_MAX_VARS);
     if (!nan_out || !outl_out || (nvar && (!vars || !q))) return pem::fail(PEM_ERR_INVALID_ARG, "pem_campaign_masks: NULL array");
     if (nvar && (q_ld < nvar || row25 < 0 || row75 < 0)) return pem::fail(PEM_ERR_INVALID_ARG, "pem_campaign_masks: rows of q hold nvar values, q_ld apart");
     if ((row_certain != nullptr) != (row_uncertain != nullptr) || (row_certain && (!open_rows || !open_count || cap < 0)))
         return pem::fail(PEM_ERR_INVALID_ARG, "pem_campaign_masks: the premask counts come with open_rows and open_count");
+    if (mask_ld < n) return pem::fail(PEM_ERR_INVALID_ARG, "pem_campaign_masks: rows of the mask arrays shorter than n");
     if (n == 0) return PEM_OK;
     if (int rc = pem::check_device()) return rc;
     CampaignVars cv{};
@@ -167,10 +211,19 @@ extern "C" int pem_campaign_masks_f64_dev(size_t n, int nvar, const double* cons
     }
     int cus = 0;
     HIP_TRY(pem::device_cus(&cus));
-    long long blocks = ((long long)n + MBLOCK - 1) / MBLOCK;
-    if (blocks > (long long)cus * 8) blocks = (long long)cus * 8;
-    hipLaunchKernelGGL(campaign_masks_kernel, dim3((unsigned)blocks), dim3(MBLOCK), 0, static_cast<hipStream_t>(stream), (long long)n, nvar, cv, q, q_ld,
-                       row25, row75, iqr_factor, nan_out, outl_out, row_certain, row_uncertain, thresh, (long long*)open_rows, (int*)open_count, cap);
+    // four samples per thread and 4-byte mask stores when every row of the mask arrays starts on a 4-byte boundary
+    const bool words = mask_ld % 4 == 0 && reinterpret_cast<uintptr_t>(nan_out) % 4 == 0 && reinterpret_cast<uintptr_t>(outl_out) % 4 == 0 &&
+                       reinterpret_cast<uintptr_t>(row_certain) % 4 == 0 && reinterpret_cast<uintptr_t>(row_uncertain) % 4 == 0;
+    const int v = words ? 4 : 1;
+    long long blocks = (((long long)n + v - 1) / v + MBLOCK - 1) / MBLOCK;
+    if (blocks > (long long)cus * 16) blocks = (long long)cus * 16;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (words)
+        hipLaunchKernelGGL(campaign_masks_kernel<4>, dim3((unsigned)blocks), dim3(MBLOCK), 0, st, (long long)n, nvar, cv, q, q_ld, row25, row75, iqr_factor,
+                           nan_out, outl_out, mask_ld, row_certain, row_uncertain, thresh, (long long*)open_rows, (int*)open_count, cap);
+    else
+        hipLaunchKernelGGL(campaign_masks_kernel<1>, dim3((unsigned)blocks), dim3(MBLOCK), 0, st, (long long)n, nvar, cv, q, q_ld, row25, row75, iqr_factor,
+                           nan_out, outl_out, mask_ld, row_certain, row_uncertain, thresh, (long long*)open_rows, (int*)open_count, cap);
     HIP_TRY(hipGetLastError());
     return PEM_OK;
 }

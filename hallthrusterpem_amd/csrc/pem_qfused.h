@@ -90,8 +90,16 @@ __attribute__((visibility("hidden"))) int quantiles_fused(size_t n, int m, int n
                                                           int* fused_ok, hipStream_t st);
 // the plain selection (pem_quantiles_strided_f64_dev) on the SECOND workspace of the library: may run on another host thread and stream
 // while quantiles_fused is under way (the scalar QoIs of a campaign, selected while the profile's records are being sorted)
+// `plan` (optional): the first ceil(n / 32) rows exist before the rest does -- a campaign's pilot evaluation wrote them -- so the
+// selection takes its pilot form with THOSE rows as the subsample (exchangeable rows: a Monte-Carlo design) and calls
+// `before_full(ctx, st)` before its first pass over all n rows: the caller blocks there until the launch that writes them is
+// under way and makes `st` wait for it.  The subsample's passes then run while that launch does.
+struct SidePlan {
+    int (*before_full)(void* ctx, hipStream_t st) = nullptr;
+    void* ctx = nullptr;
+};
 __attribute__((visibility("hidden"))) int quantiles_side(size_t n, int m, const double* data, size_t ld, size_t cs, int nq,
                                                          const uint64_t* rank_prev, const uint64_t* rank_next, const double* gamma, double* out,
-                                                         hipStream_t st);
+                                                         hipStream_t st, const SidePlan* plan = nullptr);
 
 }  // namespace pem

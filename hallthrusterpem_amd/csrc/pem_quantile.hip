@@ -1322,7 +1322,7 @@ QWork g_qwork[2];
 
 static int quantiles_impl(size_t n, int m, const double* data, size_t ld, size_t cs, int nq, const uint64_t* rank_prev,
                           const uint64_t* rank_next, const double* gamma, double* out, pem_stream_t stream, pem::FusedProducer* fused,
-                          int* fused_ok, int slot = 0) {
+                          int* fused_ok, int slot = 0, const pem::SidePlan* plan = nullptr) {
     if (m < 1 || m > 64 * MAX_NC) return pem::fail(PEM_ERR_INVALID_ARG, "pem_quantiles: 1 <= m <= %d columns", 64 * MAX_NC);
     if (fused && (m > 128 || !fused_ok)) return pem::fail(PEM_ERR_INVALID_ARG, "pem_quantiles: the fused form takes up to 128 columns");
     if (cs < 1 || (cs == 1 ? ld < (size_t)m : (ld != 1 || cs < n)))
@@ -1353,7 +1353,8 @@ static int quantiles_impl(size_t n, int m, const double* data, size_t ld, size_t
         pilot = 32;
         if (const char* e = getenv("PEM_FUSED_PILOT")) pilot = atoll(e) >= 32 ? atoll(e) : 32;
     }
-    const bool use_pilot = fused ? true : (pilot >= 2 && (long long)n * m >= pilot_min && (long long)n >= 4 * pilot);
+    if (plan) pilot = 32;                                                 // (the rows the plan's caller has written: 0 .. ceil(n / 32) - 1)
+    const bool use_pilot = fused ? true : plan ? (long long)n >= 4 * pilot : (pilot >= 2 && (long long)n * m >= pilot_min && (long long)n >= 4 * pilot);
     if (fused && (long long)n < 4 * pilot) return pem::fail(PEM_ERR_INVALID_ARG, "pem_quantiles: the fused form needs at least %lld rows", 4 * pilot);
 
     // workspace: columns | targets | hist1 | hist2 | total, outside | brackets | below | histA -- kept between calls (grow-only,
@@ -1543,6 +1544,8 @@ static int quantiles_impl(size_t n, int m, const double* data, size_t ld, size_t
 
     int path = 0;
     bool answered = false;
+    if (plan && !use_pilot && plan->before_full)                           // (too few rows for a subsample: everything is awaited)
+        if (int rc = plan->before_full(plan->ctx, st)) return cleanup(rc);
     if (use_pilot) {
         // 1. the subsample's order statistics around every wanted quantile: 7 standard deviations of the subsample's rank, + 8
         const size_t rows_p = (n + (size_t)pilot - 1) / (size_t)pilot;
@@ -1565,6 +1568,10 @@ static int quantiles_impl(size_t n, int m, const double* data, size_t ld, size_t
             if (int rc = fused->pilot(rows_p, const_cast<double*>(data), st)) return cleanup(rc);
             const bool edges = !(getenv("PEM_FUSED_PILOT_EXACT") && atoi(getenv("PEM_FUSED_PILOT_EXACT")));
             if (int rc = four_passes(rows_p, ld, pw, edges)) return rc;
+        } else if (plan) {                                                  // the FIRST rows_p rows are the subsample; the rest is awaited
+            if (int rc = four_passes(rows_p, ld, pw)) return rc;
+            if (plan->before_full)
+                if (int rc = plan->before_full(plan->ctx, st)) return cleanup(rc);
         } else if (int rc = four_passes(rows_p, ld * (size_t)pilot, pw)) return rc;
         // 2. pass A over everything: below / inside counts; the ranks inside their brackets become sub-bins
         const dim3 grid = grid_for(n);
@@ -1766,8 +1773,8 @@ int pem::quantiles_fused(size_t n, int m, int nq, const uint64_t* rank_prev, con
 }
 
 int pem::quantiles_side(size_t n, int m, const double* data, size_t ld, size_t cs, int nq, const uint64_t* rank_prev, const uint64_t* rank_next,
-                        const double* gamma, double* out, hipStream_t st) {
-    return quantiles_impl(n, m, data, ld, cs, nq, rank_prev, rank_next, gamma, out, static_cast<pem_stream_t>(st), nullptr, nullptr, 1);
+                        const double* gamma, double* out, hipStream_t st, const pem::SidePlan* plan) {
+    return quantiles_impl(n, m, data, ld, cs, nq, rank_prev, rank_next, gamma, out, static_cast<pem_stream_t>(st), nullptr, nullptr, 1, plan);
 }
 
 extern "C" int pem_quantiles_f64_dev(size_t n, int m, const double* data, size_t ld, int nq, const uint64_t* rank_prev, const uint64_t* rank_next,

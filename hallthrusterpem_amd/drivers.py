@@ -350,8 +350,9 @@ def forward_uq_statistics(n: int, seed: int = 0, keep_profile: bool = True, perc
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev)
         # (what the masks pass below writes is allocated before the evaluation is enqueued: nothing between the two calls but the call)
-        nan_s = torch.empty((nv + 1, n), dtype=torch.bool, device=dev)      # rows: the scalar outputs, then the profile
-        out_s = torch.empty((nv + 1, n), dtype=torch.bool, device=dev)
+        n_pad = (n + 3) // 4 * 4                                            # (rows on 4-byte boundaries: the pass writes words)
+        nan_s = torch.empty((nv + 1, n_pad), dtype=torch.bool, device=dev)[:, :n]      # rows: the scalar outputs, then the profile
+        out_s = torch.empty((nv + 1, n_pad), dtype=torch.bool, device=dev)[:, :n]
         open_rows = torch.empty(cap, dtype=torch.int64, device=dev)
         open_count = torch.zeros(1, dtype=torch.int32, device=dev)
         if fused and n >= FUSED_STATS_MIN_N:
@@ -401,7 +402,7 @@ def forward_uq_statistics(n: int, seed: int = 0, keep_profile: bool = True, perc
     with torch.cuda.device(dev):
         vars_ = (C.c_void_p * nv)(*[batch.qoi[i].data_ptr() for i in range(nv)])
         _lib.check(_lib.load().pem_campaign_masks_f64_dev(
-            n, nv, vars_, dp(qs), qs.stride(0), 0, 1, float(iqr_factor), dp(nan_s), dp(out_s), dp(certain) if premasked else None,
+            n, nv, vars_, dp(qs), qs.stride(0), 0, 1, float(iqr_factor), dp(nan_s), dp(out_s), nan_s.stride(0), dp(certain) if premasked else None,
             dp(uncertain) if premasked else None, thresh, dp(open_rows), dp(open_count), cap, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
     for i, k in enumerate(QOI_NAMES):
         nan_idx[k], outlier_idx[k] = nan_s[i], out_s[i]

@@ -362,14 +362,14 @@ int pem_row_masks_f64_dev(size_t n, int m, const double* data, size_t ld, const 
  * (drivers.forward_uq_statistics; gen_data.py:150-168 for variables of one entry per sample): vars: HOST array of nvar <= 8 device
  * pointers to n values each; q: the variables' percentiles on the device, rows of nvar values q_ld apart (pem_coupled_mc_stats_f64_dev's
  * q_scalars), of which rows row25 / row75 are the quartiles: the bounds are p25 - f iqr and p75 + f iqr, rounded as numpy rounds them;
- * nan_out / outl_out [nvar][n] bytes (0 / 1: np.isnan(x); (x < lo) | (x > hi)).  With row_certain / row_uncertain (the per-sample counts
+ * nan_out / outl_out [nvar][mask_ld] bytes, mask_ld >= n (a multiple of 4 lets the pass write words) (0 / 1: np.isnan(x); (x < lo) | (x > hi)).  With row_certain / row_uncertain (the per-sample counts
  * of pem_coupled_mc_stats_f64_dev's premask; both or neither) the arrays have one row more, the profile's: nan_out[nvar][i] = 0,
  * outl_out[nvar][i] = certain > thresh, and the samples with certain <= thresh < certain + uncertain -- whose verdict the exact bounds
  * must settle -- are appended to open_rows (int64, room for `cap`; unordered) and counted in *open_count (device int32, zeroed by the
  * caller; more than cap: the list is incomplete).  Asynchronous on `stream`.                                                       */
 int pem_campaign_masks_f64_dev(size_t n, int nvar, const double* const* vars, const double* q, int q_ld, int row25, int row75,
                                double iqr_factor, uint8_t* nan_out,
-                               uint8_t* outl_out, const uint8_t* row_certain, const uint8_t* row_uncertain, int thresh,
+                               uint8_t* outl_out, size_t mask_ld, const uint8_t* row_certain, const uint8_t* row_uncertain, int thresh,
                                int64_t* open_rows, int32_t* open_count, int cap, pem_stream_t stream);
 
 /* The multi-rank building blocks of the same selection (samples sharded over GPUs; hallthrusterpem_amd/percentiles.py drives the

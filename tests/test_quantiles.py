@@ -548,7 +548,8 @@ def test_two_ranks_sharing_the_gpu_get_the_percentiles_of_the_whole_campaign(tmp
 
 
 @pytest.mark.gpu
-def test_campaign_masks_entry_point_equals_numpy():
+@pytest.mark.parametrize('pad', [0, 1], ids=['rows_n_apart', 'rows_on_4_byte_boundaries'])
+def test_campaign_masks_entry_point_equals_numpy(pad):
     """pem_campaign_masks_f64_dev: the masks of scalar outputs (NaN; outside p25 - f iqr .. p75 + f iqr with numpy's roundings) and the
     verdict of the premask counts (outlier for certain, settled, or listed as open), against numpy on crafted arrays."""
     import ctypes as C
@@ -564,15 +565,16 @@ def test_campaign_masks_entry_point_equals_numpy():
     uncertain = np.minimum(91 - certain, rng.integers(0, 4, n)).astype(np.uint8)
     xd, qd = torch.from_numpy(x).cuda(), torch.from_numpy(q).cuda()
     cd, ud = torch.from_numpy(certain).cuda(), torch.from_numpy(uncertain).cuda()
-    nan_o = torch.full((nv + 1, n), 7, dtype=torch.uint8, device='cuda')
-    out_o = torch.full((nv + 1, n), 7, dtype=torch.uint8, device='cuda')
+    pitch = n + pad                                           # (100 004: the pass writes 4-byte words; 100 003: bytes)
+    nan_o = torch.full((nv + 1, pitch), 7, dtype=torch.uint8, device='cuda')[:, :n]
+    out_o = torch.full((nv + 1, pitch), 7, dtype=torch.uint8, device='cuda')[:, :n]
     cap = 64
     rows = torch.full((cap,), -1, dtype=torch.int64, device='cuda')
     count = torch.zeros(1, dtype=torch.int32, device='cuda')
     p = lambda t: C.c_void_p(t.data_ptr())                                                   # noqa: E731
     vars_ = (C.c_void_p * nv)(*[xd[i].data_ptr() for i in range(nv)])
     lib = _lib.load()
-    _lib.check(lib.pem_campaign_masks_f64_dev(n, nv, vars_, p(qd), qd.stride(0), 0, 1, f, p(nan_o), p(out_o), p(cd), p(ud), thresh, p(rows), p(count),
+    _lib.check(lib.pem_campaign_masks_f64_dev(n, nv, vars_, p(qd), qd.stride(0), 0, 1, f, p(nan_o), p(out_o), nan_o.stride(0), p(cd), p(ud), thresh, p(rows), p(count),
                                               cap, None))
     torch.cuda.synchronize()
     iqr = q[1] - q[0]
@@ -590,13 +592,13 @@ def test_campaign_masks_entry_point_equals_numpy():
     # a list that fits; without the premask counts the profile's row is left alone
     rows2 = torch.full((open_want.size + 8,), -1, dtype=torch.int64, device='cuda')
     count.zero_()
-    _lib.check(lib.pem_campaign_masks_f64_dev(n, nv, vars_, p(qd), qd.stride(0), 0, 1, f, p(nan_o), p(out_o), p(cd), p(ud), thresh, p(rows2), p(count),
+    _lib.check(lib.pem_campaign_masks_f64_dev(n, nv, vars_, p(qd), qd.stride(0), 0, 1, f, p(nan_o), p(out_o), nan_o.stride(0), p(cd), p(ud), thresh, p(rows2), p(count),
                                               rows2.numel(), None))
     assert np.array_equal(np.sort(rows2[:int(count.item())].cpu().numpy()), open_want)
     nan_o.fill_(7)
-    _lib.check(lib.pem_campaign_masks_f64_dev(n, nv, vars_, p(qd), qd.stride(0), 0, 1, f, p(nan_o), p(out_o), None, None, thresh, None, None, 0, None))
+    _lib.check(lib.pem_campaign_masks_f64_dev(n, nv, vars_, p(qd), qd.stride(0), 0, 1, f, p(nan_o), p(out_o), nan_o.stride(0), None, None, thresh, None, None, 0, None))
     torch.cuda.synchronize()
     assert bool((nan_o[nv] == 7).all()) and np.array_equal(nan_o[:nv].cpu().numpy().astype(bool), np.isnan(x))
-    assert lib.pem_campaign_masks_f64_dev(n, 9, vars_, p(qd), qd.stride(0), 0, 1, f, p(nan_o), p(out_o), None, None, thresh, None, None, 0, None) == 1
-    assert lib.pem_campaign_masks_f64_dev(n, nv, vars_, p(qd), 2, 0, 1, f, p(nan_o), p(out_o), None, None, thresh, None, None, 0, None) == 1
-    assert lib.pem_campaign_masks_f64_dev(n, nv, vars_, p(qd), qd.stride(0), 0, 1, f, p(nan_o), p(out_o), p(cd), None, thresh, None, None, 0, None) == 1
+    assert lib.pem_campaign_masks_f64_dev(n, 9, vars_, p(qd), qd.stride(0), 0, 1, f, p(nan_o), p(out_o), nan_o.stride(0), None, None, thresh, None, None, 0, None) == 1
+    assert lib.pem_campaign_masks_f64_dev(n, nv, vars_, p(qd), 2, 0, 1, f, p(nan_o), p(out_o), nan_o.stride(0), None, None, thresh, None, None, 0, None) == 1
+    assert lib.pem_campaign_masks_f64_dev(n, nv, vars_, p(qd), qd.stride(0), 0, 1, f, p(nan_o), p(out_o), nan_o.stride(0), p(cd), None, thresh, None, None, 0, None) == 1
