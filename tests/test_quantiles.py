@@ -329,6 +329,10 @@ def test_fused_campaign_statistics_equal_numpy(n, keep):
     for k in got['nan_idx']:
         assert torch.equal(got['nan_idx'][k], nan_a[k]) and torch.equal(got['outlier_idx'][k], outl_a[k]), k
     assert set(got['nan_idx']) == {'V_cc', 'div_angle', 'T_c', 'j_ion'} and got['premasked'] is got['fused']
+    if n == 70_001:                                          # the sampled inputs, when asked for, are the plain campaign's
+        refx = drivers.forward_uq(n, seed=21, keep_profile=False, keep_inputs=True)
+        gotx = drivers.forward_uq_statistics(n, seed=21, keep_profile=keep, keep_inputs=True)
+        assert gotx['fused'] and torch.equal(gotx['x'], refx['x']) and torch.equal(gotx['bands']['j_ion'], got['bands']['j_ion'])
 
 
 def test_fused_campaign_statistics_decline_and_fall_back(monkeypatch):
@@ -349,9 +353,12 @@ def test_fused_campaign_statistics_decline_and_fall_back(monkeypatch):
     small = drivers.forward_uq_statistics(n, seed=6, keep_profile=True)
     monkeypatch.delenv('PEM_QUANTILE_RECORD_CAP')
     assert small['fused'] is False
-    ext = drivers.forward_uq_statistics(n, seed=6, keep_profile=True, percentiles=(0.0, 1.0, 99.0, 100.0))
-    assert ext['fused'] is False                                                # (the brackets of 0 % and 1 % overlap)
-    assert np.array_equal(ext['bands']['j_ion'].cpu().numpy(), np.percentile(ext['j_ion'].cpu().numpy(), [0.0, 1.0, 99.0, 100.0], axis=0))
+    ext = drivers.forward_uq_statistics(n, seed=6, keep_profile=True, percentiles=(0.0, 0.2, 99.8, 100.0))
+    assert ext['fused'] is False                                                # (the brackets of 0 % and 0.2 % overlap)
+    assert np.array_equal(ext['bands']['j_ion'].cpu().numpy(), np.percentile(ext['j_ion'].cpu().numpy(), [0.0, 0.2, 99.8, 100.0], axis=0))
+    ends = drivers.forward_uq_statistics(n, seed=6, keep_profile=True, percentiles=(0.0, 1.0, 99.0, 100.0))
+    assert ends['fused'] is True                                                # (minimum and maximum: brackets open at one end, counted on chip)
+    assert np.array_equal(ends['bands']['j_ion'].cpu().numpy(), np.percentile(ends['j_ion'].cpu().numpy(), [0.0, 1.0, 99.0, 100.0], axis=0))
     ok = drivers.forward_uq_statistics(n, seed=6, keep_profile=True, percentiles=(2.0, 40.0, 60.0, 98.0))
     assert ok['fused'] is True and ok['premasked'] is False and torch.equal(ok['j_ion'], small['j_ion'])      # six brackets: no premask
     assert np.array_equal(ok['bands']['j_ion'].cpu().numpy(), np.percentile(ok['j_ion'].cpu().numpy(), [2.0, 40.0, 60.0, 98.0], axis=0))
