@@ -2016,6 +2016,20 @@ struct Stage {
     }
 } g_stage;   // guarded by g_ws.mu
 
+// Small calls skip the copies altogether: the kernels read their inputs from the pinned staging buffer and write their results
+// to it over PCIe (hipHostMalloc memory is device-accessible at its host address and coherent), so a call is memcpy in, ONE launch,
+// a stream synchronisation, memcpy out -- without the two copy-engine round trips: the calls amisc makes while it trains (a few to a
+// few hundred samples) go from 33-35 to 27-29 us (cathode_coupling) and from 60-63 to 54-59 us (pem_v0_coupled), n = 1000: 113-148 ->
+// 95-108 us (tools/latency_probe.py, interleaved; profiles/latency_r04.txt).  At 560 KB of footprint (BASELINE configs[0]: 1e4 cathode
+// samples) the kernels' reads over the link cost what the copies saved: ZC_BYTES stays below that.  PEM_ZERO_COPY=0 switches it off.
+constexpr size_t ZC_BYTES = size_t(256) << 10;
+unsigned char* host_call_base(size_t footprint) {          // where a host-pointer call carves its arrays: g_ws.mu held, g_ws reserved
+    static const bool on = !(getenv("PEM_ZERO_COPY") && atoi(getenv("PEM_ZERO_COPY")) == 0);
+    if (on && footprint <= ZC_BYTES)
+        if (unsigned char* pin = g_stage.get()) return pin;
+    return static_cast<unsigned char*>(static_cast<void*>(g_ws.buf));
+}
+
 struct Mover {
     unsigned char* ws;
     unsigned char* pin;       // staging for the inputs, or nullptr: array-by-array copies
@@ -2043,7 +2057,7 @@ struct Mover {
         return PEM_OK;
     }
     int flush_in() {
-        if (pin && in_hi > in_lo) HIP_TRY(hipMemcpyAsync(ws + in_lo, pin + in_lo, in_hi - in_lo, hipMemcpyHostToDevice, nullptr));
+        if (pin && pin != ws && in_hi > in_lo) HIP_TRY(hipMemcpyAsync(ws + in_lo, pin + in_lo, in_hi - in_lo, hipMemcpyHostToDevice, nullptr));
         return PEM_OK;
     }
     int out(void* host, const void* dev, size_t bytes) {
@@ -2058,7 +2072,7 @@ struct Mover {
         return PEM_OK;
     }
     int finish() {
-        if (pin_out && out_hi > out_lo)
+        if (pin_out && pin_out != ws && out_hi > out_lo)       // (ws == pin: the zero-copy form -- the kernels wrote there)
             HIP_TRY(hipMemcpyAsync(pin_out + out_lo, ws + out_lo, out_hi - out_lo, hipMemcpyDeviceToHost, nullptr));
         HIP_TRY(hipStreamSynchronize(nullptr));
         for (int i = 0; i < nout; ++i) memcpy(outs[i].host, pin_out + outs[i].off, outs[i].bytes);
@@ -2750,15 +2764,16 @@ int pem_cathode_f64(size_t n, const double* P_b, const double* V_a, const double
     std::lock_guard<std::mutex> lock(g_ws.mu);
     const size_t chunk = n < (size_t(1) << 24) ? n : (size_t(1) << 24);
     if (int rc = g_ws.reserve(7 * padded(chunk * 8))) return rc;
+    unsigned char* const base = host_call_base(7 * padded(chunk * 8));
     const double* in[6] = {P_b, V_a, T_e, V_vac, Pstar, P_T};
     for (size_t off = 0; off < n; off += chunk) {
         const size_t m = (n - off < chunk) ? n - off : chunk;
-        Carver cv(g_ws.buf);
+        Carver cv(base);
         double* d[7];
         for (int i = 0; i < 6; ++i) d[i] = cv.take<double>(chunk);
         const size_t in_end = cv.off;
         d[6] = cv.take<double>(chunk);
-        Mover mv(g_ws.buf, in_end, cv.off);
+        Mover mv(base, in_end, cv.off);
         for (int i = 0; i < 6; ++i) PEM_TRY(mv.in(in[i] + off, d[i], m * 8));
         PEM_TRY(mv.flush_in());
         if (int rc = pem_cathode_f64_dev(m, d[0], d[1], d[2], d[3], d[4], d[5], torr2pa, d[6], nullptr)) return rc;
@@ -2778,16 +2793,17 @@ int pem_thruster_f64(size_t n, const double* V_a, const double* V_cc, const doub
     std::lock_guard<std::mutex> lock(g_ws.mu);
     const size_t chunk = n < (size_t(1) << 24) ? n : (size_t(1) << 24);
     if (int rc = g_ws.reserve(12 * padded(chunk * 8))) return rc;
+    unsigned char* const base = host_call_base(12 * padded(chunk * 8));
     const double* in[4] = {V_a, V_cc, mdot_a, a_1};
     double* out[8] = {I_B0, I_d, T, eta_c, eta_m, eta_v, eta_a, v_exh};
     for (size_t off = 0; off < n; off += chunk) {
         const size_t m = (n - off < chunk) ? n - off : chunk;
-        Carver cv(g_ws.buf);
+        Carver cv(base);
         double *di[4], *dout[8];
         for (auto& p : di) p = cv.take<double>(chunk);
         const size_t in_end = cv.off;
         for (int i = 0; i < 8; ++i) dout[i] = out[i] ? cv.take<double>(chunk) : nullptr;
-        Mover mv(g_ws.buf, in_end, cv.off);
+        Mover mv(base, in_end, cv.off);
         for (int i = 0; i < 4; ++i) PEM_TRY(mv.in(in[i] + off, di[i], m * 8));
         PEM_TRY(mv.flush_in());
         if (int rc = pem_thruster_f64_dev(m, di[0], di[1], di[2], di[3], dout[0], dout[1], dout[2], dout[3], dout[4],
@@ -2820,10 +2836,11 @@ int pem_plume_f64(size_t n, int n_radii, const double* radii, double torr2pa, co
     chunk = (chunk + 63) & ~size_t(63);
     const size_t need = 10 * padded(chunk * 8) + padded(chunk * NANG * R * 8) + 2 * padded(chunk * R * 8) + padded(chunk);
     if (int rc = g_ws.reserve(need)) return rc;
+    unsigned char* const base = host_call_base(need);
     const double* in[10] = {P_b, c0, c1, c2, c3, c4, c5, sigma_cex, I_B0, T};
     for (size_t off = 0; off < n; off += chunk) {
         const size_t m = (n - off < chunk) ? n - off : chunk;
-        Carver cv(g_ws.buf);
+        Carver cv(base);
         double* d[10];
         for (auto& p : d) p = cv.take<double>(chunk);
         const size_t in_end = cv.off;
@@ -2831,7 +2848,7 @@ int pem_plume_f64(size_t n, int n_radii, const double* radii, double torr2pa, co
         double* ddiv = cv.take<double>(chunk * R);
         double* dtc = cv.take<double>(chunk * R);
         uint8_t* dinv = cv.take<uint8_t>(chunk);
-        Mover mv(g_ws.buf, in_end, cv.off);
+        Mover mv(base, in_end, cv.off);
         for (int i = 0; i < 10; ++i)
             if (in[i]) PEM_TRY(mv.in(in[i] + off, d[i], m * 8));
         PEM_TRY(mv.flush_in());
@@ -2865,9 +2882,10 @@ int pem_coupled_f64(size_t n, double torr2pa, double radius, const double* P_b, 
     chunk = (chunk + 63) & ~size_t(63);
     const size_t need = 20 * padded(chunk * 8) + padded(chunk * NANG * 8) + padded(chunk);
     if (int rc = g_ws.reserve(need)) return rc;
+    unsigned char* const base = host_call_base(need);
     for (size_t off = 0; off < n; off += chunk) {
         const size_t m = (n - off < chunk) ? n - off : chunk;
-        Carver cv(g_ws.buf);
+        Carver cv(base);
         double* d[15];
         for (auto& p : d) p = cv.take<double>(chunk);
         const size_t in_end = cv.off;
@@ -2878,7 +2896,7 @@ int pem_coupled_f64(size_t n, double torr2pa, double radius, const double* P_b, 
         double* dtc = cv.take<double>(chunk);
         uint8_t* dinv = cv.take<uint8_t>(chunk);
         double* dj = cv.take<double>(chunk * NANG);   // last: without a profile the staged copy-back stops before it
-        Mover mv(g_ws.buf, in_end, cv.off);
+        Mover mv(base, in_end, cv.off);
         for (int i = 0; i < 15; ++i) PEM_TRY(mv.in(in[i] + off, d[i], m * 8));
         PEM_TRY(mv.flush_in());
         if (int rc = pem_coupled_f64_dev(m, torr2pa, radius, d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], d[9],

@@ -21,7 +21,8 @@
  *   - `*_dev` functions take DEVICE pointers (HBM of the current HIP device) and enqueue on
  *     `stream` (a hipStream_t passed as void*; NULL = the default stream) without synchronising.
  *     Functions without the suffix take HOST pointers, stage through device memory and return
- *     after the results are back in the caller's buffers.
+ *     after the results are back in the caller's buffers (calls of up to 256 KB of arrays: the
+ *     kernels work on a pinned host buffer directly, without the two copies).
  *   - Nothing is retained past the call.  Inputs are never written.
  *   - j_ion is laid out [n][91][n_radii] (row-major), exactly numpy's (..., 91, R) result of
  *     plume.py:102; angle k is k degrees from the thruster centreline (plume.py:53).
