@@ -2568,6 +2568,7 @@ int side_stream(hipStream_t* out) {
 struct McProducer : pem::FusedProducer {
     pem::McLaunch a;
     bool store_profile;
+    bool counted = false;                          // the counting launch is under way: every output but the percentiles gets written
     ScalarJob* job = nullptr;
     int pilot(size_t rows, double* dst, hipStream_t st) override {
         pem::McLaunch p = a;                       // samples 0 .. rows-1 of the same design; their profile rows go to dst
@@ -2579,6 +2580,7 @@ struct McProducer : pem::FusedProducer {
     int waves(int nq, unsigned* w) override { return pem::coupled_count_waves(a.n, nq, store_profile, w); }
     int count(const pem::CountIO& io, hipStream_t st) override {
         if (int rc = pem::launch_coupled_mc_count(a, io, store_profile, st)) return rc;
+        counted = true;
         return job ? job->full.launched(st) : PEM_OK;    // (the side selection's passes over all samples may follow this launch)
     }
 };
@@ -2664,13 +2666,10 @@ int pem_coupled_mc_stats_f64_dev(size_t n, uint64_t first_index, uint64_t seed, 
     if (int rc = pem::quantiles_fused(n, NANG, nq, rank_prev, rank_next, gamma, j_ion ? j_ion : pilot_rows, prod, q_out, fused_ok, st))
         return rc;                                 // (~ScalarJob tells the worker to give up and joins it)
     if (premask_ok) *premask_ok = (*fused_ok && prod.pm_done) ? 1 : 0;
-    if (!*fused_ok) {
-        // declined -- possibly before the counting launch, with nothing but the pilot's samples evaluated: the plain launch makes
-        // every output complete (a rare path: 1.5 ms per 1e7 samples where the counting launch had already run).  A scalar selection
-        // that went on behind the counting launch is let finish first (the plain launch writes the same scalars again).
-        if (q_scalars && job.full.signalled) {
-            if (int rc = job.join()) return fail(rc, "%s", job.error.c_str());
-        }
+    if (!*fused_ok && !prod.counted) {
+        // declined before the counting launch (the fused form refused the call's shape), with nothing but the pilot's samples evaluated:
+        // the plain launch makes every output complete.  (Declined AFTER it -- unfit brackets, a rank outside its bracket, record
+        // overflow, a non-finite value -- the counting launch has written every output already; only the percentiles are missing.)
         if (int rc = pem::launch_coupled_mc(prod.a, st)) return rc;
         if (q_scalars) {
             if (int rc = job.pilot.launched(st)) return rc;               // (no-ops for a stage that has been released)

@@ -1588,6 +1588,7 @@ static int quantiles_impl(size_t n, int m, const double* data, size_t ld, size_t
     hipLaunchKernelGGL((bracket_hist_kernel<NC_, NQ_>), grid, blk, ldsA, st, (long long)n, m, ld, cs, data, br, any_single, binsA, col, below, histA)
 #define Q_BRHIST(NC_) Q_BY_NQ_##NC_(Q_BRHIST_, NC_)
         unsigned rcap = 0;
+        bool pm_launched = false;                                           // fused form: the counting launch carried the premask
         if (!fused) {
             Q_BY_NC(Q_BRHIST);
         } else {
@@ -1599,15 +1600,12 @@ static int quantiles_impl(size_t n, int m, const double* data, size_t ld, size_t
             if (want_pm)
                 hipLaunchKernelGGL(premask_bounds_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, st, m, nq, br, fused->pm_q25, fused->pm_q75,
                                    fused->pm_factor, pm_thr, pm_bad);
-            int h_unfit4[4] = {0, 0, 0, 0};                                // unfit | producer flags (2) | premask bounds unfit
-            Q_TRY(hipMemcpyAsync(h_unfit4, unfit, sizeof h_unfit4, hipMemcpyDeviceToHost, st));
-            Q_TRY(hipStreamSynchronize(st));
-            const int h_unfit = h_unfit4[0];
-            const bool use_pm = want_pm && h_unfit4[3] == 0;
-            if (h_unfit) {
-                *fused_ok = 0;
-                return cleanup(PEM_OK);
-            }
+            // (No host round trip here -- it cost every campaign 40 us of an idle GPU: whether the brackets are fit for the producer and
+            // the premask's bounds usable is read back WITH the counts, after the counting launch.  Unfit brackets -- heavy ties,
+            // overlapping percentiles -- are counted against all the same, harmlessly, and the run is then declined: the producer's
+            // launch has written every output but the percentiles by then.)
+            const bool use_pm = want_pm;
+            pm_launched = want_pm;
             // record room per wave: the brackets hold `expected` values of the array (their ranks in the subsample say so) -- half as
             // much again, and a few thousand for the waves that get more than their share
             double expected = 0.0;
@@ -1634,7 +1632,6 @@ static int quantiles_impl(size_t n, int m, const double* data, size_t ld, size_t
                 cio.premask = pm_thr;
                 cio.row_certain = fused->pm_certain;
                 cio.row_uncertain = fused->pm_uncertain;
-                fused->pm_done = 1;
             }
             if (int rc = fused->count(cio, st)) return cleanup(rc);
             int cus = 256;
@@ -1675,12 +1672,13 @@ static int quantiles_impl(size_t n, int m, const double* data, size_t ld, size_t
         hipLaunchKernelGGL(layout_kernel, dim3(1), dim3(64 * MAX_NC), 0, st, m, nt, tg, total);
         Q_TRY(hipGetLastError());
         u64 h_tot[2] = {0, 0};
-        int h_prod[2] = {0, 0};
+        int h_unfit4[4] = {0, 0, 0, 0};                                    // fused form: unfit | producer flags (2) | premask bounds unfit
         Q_TRY(hipMemcpyAsync(h_tot, total, 2 * sizeof(u64), hipMemcpyDeviceToHost, st));
-        if (fused) Q_TRY(hipMemcpyAsync(h_prod, prod_flags, sizeof h_prod, hipMemcpyDeviceToHost, st));
+        if (fused) Q_TRY(hipMemcpyAsync(h_unfit4, unfit, sizeof h_unfit4, hipMemcpyDeviceToHost, st));
         Q_TRY(hipStreamSynchronize(st));
-        if (fused && ((int)(h_tot[1] & 0xffffffffull) != 0 || h_prod[0] || h_prod[1])) {
-            *fused_ok = 0;                                                  // a rank outside its bracket, record overflow, a non-finite sample
+        if (fused) fused->pm_done = (pm_launched && h_unfit4[3] == 0) ? 1 : 0;
+        if (fused && (h_unfit4[0] || (int)(h_tot[1] & 0xffffffffull) != 0 || h_unfit4[1] || h_unfit4[2])) {
+            *fused_ok = 0;                     // unfit brackets, a rank outside its bracket, record overflow, a non-finite sample
             return cleanup(PEM_OK);
         }
         if ((int)(h_tot[1] & 0xffffffffull) == 0) {
