@@ -2531,21 +2531,28 @@ struct ScalarJob {
         }
     };
     Stage pilot, full;
+    // The other direction: the counting launch must not START while the side selection's subsample passes are still running -- their
+    // histograms take most of a CU's LDS, a workgroup of the persistent counting grid that finds no room waits for a whole pass of its
+    // neighbours, and the launch takes 4 ms instead of 2.3 (seen in two calls of seven under the profiler, whose host threads are
+    // slow).  The worker marks the end of those passes (`side`: released by the worker, awaited by the calling thread).
+    Stage side;
     std::thread worker;
     int rc = PEM_OK;
     std::string error;
     int create() {
         HIP_TRY(hipEventCreateWithFlags(&pilot.ev, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&full.ev, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&side.ev, hipEventDisableTiming));
         return PEM_OK;
     }
     int join() {
         pilot.signal(0);
         full.signal(0);
         if (worker.joinable()) worker.join();
-        if (pilot.ev) (void)hipEventDestroy(pilot.ev);
-        if (full.ev) (void)hipEventDestroy(full.ev);
-        pilot.ev = full.ev = nullptr;
+        for (Stage* s : {&pilot, &full, &side}) {
+            if (s->ev) (void)hipEventDestroy(s->ev);
+            s->ev = nullptr;
+        }
         return rc;
     }
     ~ScalarJob() { (void)join(); }
@@ -2579,6 +2586,7 @@ struct McProducer : pem::FusedProducer {
     }
     int waves(int nq, unsigned* w) override { return pem::coupled_count_waves(a.n, nq, store_profile, w); }
     int count(const pem::CountIO& io, hipStream_t st) override {
+        if (job && job->worker.joinable() && job->side.gone.get() == 1) HIP_TRY(hipStreamWaitEvent(st, job->side.ev, 0));   // (see ScalarJob::side)
         if (int rc = pem::launch_coupled_mc_count(a, io, store_profile, st)) return rc;
         counted = true;
         return job ? job->full.launched(st) : PEM_OK;    // (the side selection's passes over all samples may follow this launch)
@@ -2615,6 +2623,10 @@ int pem_coupled_mc_stats_f64_dev(size_t n, uint64_t first_index, uint64_t seed, 
         if (int rc = side_stream(&side)) return rc;
         if (int rc = job.create()) return rc;
         job.worker = std::thread([&job, dev, side, n, nq, V_cc, qstride, rank_prev, rank_next, gamma, q_scalars]() {
+            struct Release {                                             // (whatever happens: the calling thread is not left waiting)
+                ScalarJob& j;
+                ~Release() { j.side.signal(0); }
+            } release{job};
             auto note = [&job](int rc) {
                 job.rc = rc;
                 if (rc != PEM_OK) job.error = pem_last_error();          // (the message lives in this thread's buffer)
@@ -2627,7 +2639,11 @@ int pem_coupled_mc_stats_f64_dev(size_t n, uint64_t first_index, uint64_t seed, 
             if (note(job.pilot.await(side))) return;
             pem::SidePlan plan;
             plan.ctx = &job;
-            plan.before_full = [](void* ctx, hipStream_t st) { return static_cast<ScalarJob*>(ctx)->full.await(st); };
+            plan.before_full = [](void* ctx, hipStream_t st) {
+                ScalarJob* j = static_cast<ScalarJob*>(ctx);
+                if (j->side.launched(st)) j->side.signal(0);             // the subsample's passes end here (on `st`, the side stream)
+                return j->full.await(st);
+            };
             (void)note(pem::quantiles_side(n, 3, V_cc, 1, (size_t)qstride, nq, rank_prev, rank_next, gamma, q_scalars, side, &plan));
         });
         prod.job = &job;

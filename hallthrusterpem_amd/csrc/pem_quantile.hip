@@ -1452,8 +1452,11 @@ static int quantiles_impl(size_t n, int m, const double* data, size_t ld, size_t
         if (cand_buf) (void)hipFree(cand_buf);
         cand_buf = nullptr;
         cand_cap = 0;
-        const hipError_t e = hipMalloc(&cand_buf, (size_t)(need + 1) * sizeof(u64));
-        if (e == hipSuccess) cand_cap = need + 1;
+        // (a quarter more than asked for: the lists of two campaigns differ by a few values, and a hipFree + hipMalloc in the middle of
+        // a call costs a device synchronisation and a millisecond)
+        const u64 room = need + need / 4 + 1024;
+        const hipError_t e = hipMalloc(&cand_buf, (size_t)room * sizeof(u64));
+        if (e == hipSuccess) cand_cap = room;
         return e;
     };
 #define Q_LDS(KERN) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
