@@ -13,6 +13,8 @@ UNPINNED for those two; the estimators used here are stated in the docstrings.
 Everything between `Design.fill` and the statistics stays in HBM: inputs are generated on the device
 (csrc/pem_sampler.hip), evaluated by one `pem_coupled_f64_dev` launch per batch, and reduced with torch.
 """
+import functools
+
 import numpy as np
 
 from . import sampling
@@ -28,8 +30,14 @@ MAX_Q, MAX_Q_WIDE = 6, 3     # include/pem_hip.h PEM_QUANTILE_MAX_Q, PEM_QUANTIL
 
 def _linear_ranks(n: int, percentiles):
     """The two order statistics numpy's method 'linear' reads per percentile of n values, and its interpolation weight
-    (numpy/lib/_function_base_impl.py: percentile -> _quantile): (rank_prev, rank_next) uint64, gamma float64."""
-    q = np.true_divide(np.atleast_1d(np.asarray(percentiles, dtype=np.float64)), np.float64(100))
+    (numpy/lib/_function_base_impl.py: percentile -> _quantile): (rank_prev, rank_next) uint64, gamma float64 (read-only:
+    a campaign loop asks for the same ones every call, so they are remembered)."""
+    return _linear_ranks_cached(int(n), tuple(float(x) for x in np.atleast_1d(np.asarray(percentiles, dtype=np.float64))))
+
+
+@functools.lru_cache(maxsize=64)
+def _linear_ranks_cached(n: int, percentiles: tuple):
+    q = np.true_divide(np.asarray(percentiles, dtype=np.float64), np.float64(100))
     if not np.all((q >= 0) & (q <= 1)):
         raise ValueError('Percentiles must be in the range [0, 100]')
     if n == 0:
@@ -42,6 +50,8 @@ def _linear_ranks(n: int, percentiles):
     gamma = virtual - prev                                  # (numpy takes the weight from the clipped index as well)
     rank_prev = np.where(prev < 0, n - 1, prev).astype(np.uint64)
     rank_next = np.where(nxt < 0, n - 1, nxt).astype(np.uint64)
+    for a in (rank_prev, rank_next, gamma):
+        a.setflags(write=False)
     return rank_prev, rank_next, gamma
 
 
