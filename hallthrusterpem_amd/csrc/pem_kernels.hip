@@ -2622,6 +2622,7 @@ int pem_coupled_mc_stats_f64_dev(size_t n, uint64_t first_index, uint64_t seed, 
         hipStream_t side = nullptr;
         if (int rc = side_stream(&side)) return rc;
         if (int rc = job.create()) return rc;
+        try {
         job.worker = std::thread([&job, dev, side, n, nq, V_cc, qstride, rank_prev, rank_next, gamma, q_scalars]() {
             struct Release {                                             // (whatever happens: the calling thread is not left waiting)
                 ScalarJob& j;
@@ -2646,6 +2647,9 @@ int pem_coupled_mc_stats_f64_dev(size_t n, uint64_t first_index, uint64_t seed, 
             };
             (void)note(pem::quantiles_side(n, 3, V_cc, 1, (size_t)qstride, nq, rank_prev, rank_next, gamma, q_scalars, side, &plan));
         });
+        } catch (const std::exception& e) {        // (no thread to be had: nothing may leave a C entry point but its return code)
+            return fail(PEM_ERR_HIP, "pem_coupled_mc_stats: could not start the scalar selection's thread: %s", e.what());
+        }
         prod.job = &job;
     }
     prod.a.n = n;

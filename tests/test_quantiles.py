@@ -609,3 +609,39 @@ def test_campaign_masks_entry_point_equals_numpy(pad):
     assert lib.pem_campaign_masks_f64_dev(n, 9, vars_, p(qd), qd.stride(0), 0, 1, f, p(nan_o), p(out_o), nan_o.stride(0), None, None, thresh, None, None, 0, None) == 1
     assert lib.pem_campaign_masks_f64_dev(n, nv, vars_, p(qd), 2, 0, 1, f, p(nan_o), p(out_o), nan_o.stride(0), None, None, thresh, None, None, 0, None) == 1
     assert lib.pem_campaign_masks_f64_dev(n, nv, vars_, p(qd), qd.stride(0), 0, 1, f, p(nan_o), p(out_o), nan_o.stride(0), p(cd), None, thresh, None, None, 0, None) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_two_host_threads_run_campaigns_at_once():
+    """The fused statistics keep process-wide buffers (two sets, each behind a mutex) and start a worker thread of their own per
+    call: two campaigns issued from two host threads at the same time serialise on those and both come out right."""
+    import threading
+    import torch
+    from hallthrusterpem_amd import drivers
+    n = 150_000
+    want = {}
+    for seed in (31, 32):
+        ref = drivers.forward_uq(n, seed=seed, keep_profile=True, keep_inputs=False)
+        want[seed] = (np.percentile(ref['j_ion'].cpu().numpy(), [5.0, 50.0, 95.0], axis=0),
+                      np.percentile(ref['T_c'].cpu().numpy(), [5.0, 50.0, 95.0], axis=0))
+    got, errors = {}, []
+
+    def run(seed, keep):
+        try:
+            for _ in range(6):
+                r = drivers.forward_uq_statistics(n, seed=seed, keep_profile=keep)
+                torch.cuda.synchronize()
+                got[seed] = (r['fused'], r['bands']['j_ion'].cpu().numpy(), r['bands']['T_c'].cpu().numpy())
+        except Exception as exc:                                       # noqa: BLE001 (reported by the main thread)
+            errors.append(exc)
+    threads = [threading.Thread(target=run, args=(31, True)), threading.Thread(target=run, args=(32, False))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=240)
+    assert not any(t.is_alive() for t in threads), 'a campaign did not come back'
+    assert not errors, errors
+    for seed in (31, 32):
+        assert got[seed][0] is True
+        assert np.array_equal(got[seed][1], want[seed][0]) and np.array_equal(got[seed][2], want[seed][1]), seed
