@@ -16,4 +16,4 @@ for _ in range(30):
     drivers.forward_uq_statistics(n, seed=2, keep_profile=keep)
 torch.cuda.synchronize()
 pr.disable()
-pstats.Stats(pr).sort_stats('cumulative').print_stats(28)
+pstats.Stats(pr).sort_stats("tottime").print_stats(32)
