@@ -37,7 +37,9 @@ typedef unsigned long long u64;
 constexpr int QBLOCK = 512;               // two waves per SIMD share one workgroup's LDS histogram
 constexpr int QWAVES = QBLOCK / 64;
 constexpr int LDS_WORDS = 36864;          // 144 KB of 32-bit counters per workgroup
-constexpr int SORT_CAP = 4096;            // keys a workgroup sorts in LDS (32 KB)
+constexpr int SORT_CAP = 4096;            // keys a workgroup's LDS sort buffer holds (32 KB)
+constexpr int SORT_DIRECT = 512;          // ... and sorts without narrowing the list first: a bitonic sort of 4096 keys is 78 passes with a
+                                          // barrier each (80 us for the 910 lists of a campaign), one 1024-bin narrowing round three
 constexpr int MAX_NC = 4;                 // columns per lane: m <= 256
 constexpr int UNROLL = 8;                 // row groups a wave requests before it consumes any (loads in flight per lane: UNROLL x NC)
 static_assert(PEM_QUANTILE_MAX_Q == 6, "hist2_kernel / compact_kernel are instantiated for 2, 4, ... 12 ranks per column");
@@ -572,7 +574,7 @@ __device__ u64 select_from(const List& list, u64 len, u64 rank, u64 top, int* sh
         const u64 inside = s_cnt;
         __syncthreads();
         if (lo >= hi) return lo;               // one value left (or, defensively, nothing)
-        if (inside <= SORT_CAP) {
+        if (inside <= SORT_DIRECT) {
             int np2 = 1;
             while (np2 < (int)inside) np2 <<= 1;
             if (threadIdx.x == 0) s_cnt = 0;
@@ -589,7 +591,7 @@ __device__ u64 select_from(const List& list, u64 len, u64 rank, u64 top, int* sh
             __syncthreads();
             return r;
         }
-        // too long for LDS: 1024-bin histogram over [lo, hi], keep the bin that holds the rank
+        // more keys than a short sort takes (or than LDS holds): 1024-bin histogram over [lo, hi], keep the bin that holds the rank
         for (int i = threadIdx.x; i < 1024; i += QBLOCK) hist[i] = 0;
         __syncthreads();
         const double inv = 1024.0 / ((double)(hi - lo) + 1.0);
@@ -598,15 +600,31 @@ __device__ u64 select_from(const List& list, u64 len, u64 rank, u64 top, int* sh
             if (k >= lo && k <= hi) atomicAdd(&hist[bin_of_d(k, lo, inv, 1024)], 1u);
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            u64 cum = 0;
-            int b = 0;
-            for (; b < 1023; ++b) {
-                if (cum + hist[b] > rank) break;
-                cum += hist[b];
+        if (threadIdx.x < 64) {                // the bin that holds the rank: one wave, 16 bins per lane, a scan over the lanes' sums
+            const int lane = threadIdx.x;
+            u64 mine = 0;
+#pragma unroll
+            for (int b = 0; b < 16; ++b) mine += hist[16 * lane + b];
+            u64 incl = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const u64 up = __shfl_up(incl, d);
+                if (lane >= d) incl += up;
             }
-            s_bin = b;
-            s_rank = rank - cum;
+            const u64 before = incl - mine;
+            // the first lane whose running total exceeds the rank owns it (the last lane, defensively, if none does)
+            const bool owns = incl > rank && before <= rank;
+            const u64 any = __ballot(owns);
+            if (any ? owns : lane == 63) {
+                u64 cum = before;
+                int b = 16 * lane;
+                for (; b < 16 * lane + 15; ++b) {
+                    if (cum + hist[b] > rank) break;
+                    cum += hist[b];
+                }
+                s_bin = b;
+                s_rank = rank - cum;
+            }
         }
         __syncthreads();
         const int keep = s_bin;
