@@ -44,6 +44,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <functional>
 #include <future>
 #include <mutex>
 #include <string>
@@ -2537,12 +2538,23 @@ struct ScalarJob {
     // slow).  The worker marks the end of those passes (`side`: released by the worker, awaited by the calling thread).
     Stage side;
     std::thread worker;
+    std::function<void()> body;                // what the worker runs
+    bool started = false;
     int rc = PEM_OK;
     std::string error;
-    int create() {
+    // Events and thread are made AFTER the pilot evaluation has been enqueued (McProducer::pilot): their 50-100 us of host time then
+    // pass while the GPU works instead of in front of the call's first kernel.
+    int start() {
+        if (started) return PEM_OK;
+        started = true;
         HIP_TRY(hipEventCreateWithFlags(&pilot.ev, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&full.ev, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&side.ev, hipEventDisableTiming));
+        try {
+            worker = std::thread(body);
+        } catch (const std::exception& e) {    // (no thread to be had: nothing may leave a C entry point but its return code)
+            return fail(PEM_ERR_HIP, "pem_coupled_mc_stats: could not start the scalar selection's thread: %s", e.what());
+        }
         return PEM_OK;
     }
     int join() {
@@ -2582,7 +2594,9 @@ struct McProducer : pem::FusedProducer {
         p.n = rows;
         p.j_ion = dst;
         if (int rc = pem::launch_coupled_mc(p, st)) return rc;
-        return job ? job->pilot.launched(st) : PEM_OK;   // (their scalars too: the side selection's subsample)
+        if (!job) return PEM_OK;
+        if (int rc = job->start()) return rc;
+        return job->pilot.launched(st);            // (their scalars too: the side selection's subsample)
     }
     int waves(int nq, unsigned* w) override { return pem::coupled_count_waves(a.n, nq, store_profile, w); }
     int count(const pem::CountIO& io, hipStream_t st) override {
@@ -2621,9 +2635,7 @@ int pem_coupled_mc_stats_f64_dev(size_t n, uint64_t first_index, uint64_t seed, 
         HIP_TRY(hipGetDevice(&dev));
         hipStream_t side = nullptr;
         if (int rc = side_stream(&side)) return rc;
-        if (int rc = job.create()) return rc;
-        try {
-        job.worker = std::thread([&job, dev, side, n, nq, V_cc, qstride, rank_prev, rank_next, gamma, q_scalars]() {
+        job.body = [&job, dev, side, n, nq, V_cc, qstride, rank_prev, rank_next, gamma, q_scalars]() {
             struct Release {                                             // (whatever happens: the calling thread is not left waiting)
                 ScalarJob& j;
                 ~Release() { j.side.signal(0); }
@@ -2646,10 +2658,7 @@ int pem_coupled_mc_stats_f64_dev(size_t n, uint64_t first_index, uint64_t seed, 
                 return j->full.await(st);
             };
             (void)note(pem::quantiles_side(n, 3, V_cc, 1, (size_t)qstride, nq, rank_prev, rank_next, gamma, q_scalars, side, &plan));
-        });
-        } catch (const std::exception& e) {        // (no thread to be had: nothing may leave a C entry point but its return code)
-            return fail(PEM_ERR_HIP, "pem_coupled_mc_stats: could not start the scalar selection's thread: %s", e.what());
-        }
+        };
         prod.job = &job;
     }
     prod.a.n = n;
@@ -2692,6 +2701,7 @@ int pem_coupled_mc_stats_f64_dev(size_t n, uint64_t first_index, uint64_t seed, 
         // overflow, a non-finite value -- the counting launch has written every output already; only the percentiles are missing.)
         if (int rc = pem::launch_coupled_mc(prod.a, st)) return rc;
         if (q_scalars) {
+            if (int rc = job.start()) return rc;
             if (int rc = job.pilot.launched(st)) return rc;               // (no-ops for a stage that has been released)
             if (int rc = job.full.launched(st)) return rc;
         }
