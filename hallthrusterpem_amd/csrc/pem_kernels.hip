@@ -2244,13 +2244,15 @@ int pem_plume_f64_dev(size_t n, int n_radii, const double* radii, double torr2pa
     }
     static const bool use_rmid = getenv("PEM_RADII_MID") ? atoi(getenv("PEM_RADII_MID")) != 0 : true;
     // (read per call: tests walk through the instantiations)
-    int rmid_min = getenv("PEM_RMID_MIN") ? atoi(getenv("PEM_RMID_MIN")) : 17;
+    int rmid_min = getenv("PEM_RMID_MIN") ? atoi(getenv("PEM_RMID_MIN")) : 13;
     if (rmid_min < WAVE / RMID_G_MAX + 1) rmid_min = WAVE / RMID_G_MAX + 1;
     if (use_rmid && n_radii >= rmid_min && n_radii > RADII_SMALL && n_radii <= RMID_MAX) {
         // S samples in flight per wave in P passes, rows staged in LDS, line-aligned 16-byte stores (plume_rmid_kernel).  The pair
         // (S, P) of the instantiated ones that fills the most lane slots, S R / (64 P): 25 radii -> five samples in two passes (125
         // of 128; round 3: two samples in one, 50 of 64), 33 -> three in two (99 of 128; one sample before: 33 of 64).
-        // From 11 radii on (PEM_RMID_MIN=11) it works but gains nothing over the kernel below (profiles/radii_mid_r03.txt).
+        // From 13 radii on (round 4, with the 10-KB tile: 13 / 14 / 15 / 16 radii 3.02 -> 3.35, 3.30 -> 3.73, 3.35 -> 3.57, 4.26 -> 4.38 TB/s
+        // against the wave-per-sample kernel below, interleaved; profiles/radii_mid_r04.txt); at 11 and 12 radii (PEM_RMID_MIN=11) it
+        // works and gains nothing.
         // Instantiated: one pass.  Two- and three-pass packings (-DPEM_RMID_MULTIPASS=1) fill 86-98 % of the lane slots where one pass
         // fills 52-80 %, and measured SLOWER at every radius count (25 radii: 3.25 against 3.69 TB/s, 33: 3.59 against 4.12, 44: 3.58
         // against 4.33; profiles/radii_mid_r04.txt): more samples share the 8 KB of staged rows, so a sample's runs get shorter (200

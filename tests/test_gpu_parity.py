@@ -526,7 +526,7 @@ def test_reduced_mode_table_and_loop_paths_agree_sample_by_sample(pem, oc):
     assert np.array_equal(b2.qoi.cpu().numpy(), b.qoi.cpu().numpy()[:, perm], equal_nan=True)
 
 
-@pytest.mark.parametrize('R', [2, 3, 4, 5, 6, 7, 8, 9, 13, 16, 17, 25, 31, 32, 33, 47, 64, 65, 70, 256, 257])
+@pytest.mark.parametrize('R', [2, 3, 4, 5, 6, 7, 8, 9, 12, 13, 16, 17, 25, 31, 32, 33, 47, 64, 65, 70, 256, 257])
 def test_sweep_radius_counts_across_the_kernel_switches(pem, oc, R):
     """sweep_radius arrays: the recurrence kernel for 2..8 radii (register blocks of 2 / 4 / 8 radii, 8- and 16-byte stores),
     the wave-per-sample kernel for 9..16 and 65..256 (whose radius loop runs in chunks of 64 lanes), the staged kernel for
