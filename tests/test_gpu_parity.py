@@ -529,8 +529,8 @@ def test_reduced_mode_table_and_loop_paths_agree_sample_by_sample(pem, oc):
 @pytest.mark.parametrize('R', [2, 3, 4, 5, 6, 7, 8, 9, 12, 13, 16, 17, 25, 31, 32, 33, 47, 64, 65, 70, 256, 257])
 def test_sweep_radius_counts_across_the_kernel_switches(pem, oc, R):
     """sweep_radius arrays: the recurrence kernel for 2..8 radii (register blocks of 2 / 4 / 8 radii, 8- and 16-byte stores),
-    the wave-per-sample kernel for 9..16 and 65..256 (whose radius loop runs in chunks of 64 lanes), the staged kernel for
-    17..64 (two / one samples in flight per wave: switch at 32; odd counts start every second sample's runs on an odd double), the lane-per-sample kernel above -- every count at a switch against the oracle, invalid samples included, also
+    the wave-per-sample kernel for 9..12 and 65..256 (whose radius loop runs in chunks of 64 lanes), the staged kernel for
+    13..64 (four / three / two / one samples in flight per wave: switches at 16, 21 and 32; odd counts start every second sample's runs on an odd double), the lane-per-sample kernel above -- every count at a switch against the oracle, invalid samples included, also
     with a ragged tile (n = 333)."""
     from hallthrusterpem_amd.models import current_density
     n = 333
@@ -549,7 +549,7 @@ def test_sweep_radius_counts_across_the_kernel_switches(pem, oc, R):
 @pytest.mark.parametrize('R,ts,rmid_min', [(17, 63, None), (17, 32, None), (25, 64, None), (25, 32, None), (33, 64, None), (33, 63, None),
                                            (11, 60, 11), (12, 64, 11), (13, 32, 11), (16, 64, 11)])
 def test_staged_radii_kernel_at_production_tile_sizes(pem, oc, monkeypatch, R, ts, rmid_min):
-    """plume_rmid_kernel (17..64 sweep radii by default) as large batches run it -- the host picks tiles of 8 samples for every
+    """plume_rmid_kernel (13..64 sweep radii by default) as large batches run it -- the host picks tiles of 8 samples for every
     n < 131072, so the cases above it never saw tiles of 16 / 32 / 64 (63 at three samples per wave), several groups per tile, or
     shuffles from lanes >= 8 -- and the instantiations for four and five samples per wave, reachable through
     PEM_RMID_MIN only (11..16 radii; six and seven were dropped).  Against the oracle, invalid samples and a ragged tile included."""
